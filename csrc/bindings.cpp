@@ -1,0 +1,89 @@
+// pybind11 module `_C`: RCCL communicator, gradient reducer and (via ops_bindings.cpp) the
+// HIP kernels, all operating on torch tensors and torch's current HIP stream.
+#include <torch/extension.h>
+
+#include "comm/rccl_comm.h"
+#include "reducer/reducer.h"
+
+namespace py = pybind11;
+using namespace dpa;
+
+void init_ops(py::module_& m);  // ops_bindings.cpp
+
+PYBIND11_MODULE(_C, m) {
+  m.doc() = "gfx950 native runtime: RCCL communicator, gradient reducer, HIP kernels";
+  m.attr("gpu_arch") = "gfx950";
+
+  py::class_<RcclComm, std::shared_ptr<RcclComm>>(m, "RcclComm")
+      .def_static("unique_id", []() { return py::bytes(RcclComm::unique_id()); })
+      .def(py::init([](py::bytes uid, int rank, int world, int device) {
+             std::string s = uid;
+             py::gil_scoped_release nogil;  // blocks until every rank has joined
+             return std::make_shared<RcclComm>(s, rank, world, device);
+           }),
+           py::arg("uid"), py::arg("rank"), py::arg("world"), py::arg("device"))
+      .def_property_readonly("rank", &RcclComm::rank)
+      .def_property_readonly("world", &RcclComm::world)
+      .def_property_readonly("device", &RcclComm::device)
+      .def("all_reduce", &RcclComm::all_reduce, py::arg("tensor"), py::arg("op") = 0)
+      .def("reduce", &RcclComm::reduce, py::arg("tensor"), py::arg("root") = 0, py::arg("op") = 0)
+      .def("broadcast", &RcclComm::broadcast, py::arg("tensor"), py::arg("root") = 0)
+      .def("gather", &RcclComm::gather, py::arg("input"), py::arg("output"), py::arg("root") = 0)
+      .def("all_gather", &RcclComm::all_gather)
+      .def("reduce_scatter", &RcclComm::reduce_scatter, py::arg("input"), py::arg("output"), py::arg("op") = 0)
+      .def("barrier", &RcclComm::barrier, py::call_guard<py::gil_scoped_release>())
+      .def("all_reduce_async", &RcclComm::all_reduce_async, py::arg("tensor"), py::arg("op"), py::arg("slot"))
+      .def("broadcast_async", &RcclComm::broadcast_async, py::arg("tensor"), py::arg("root"), py::arg("slot"))
+      .def("wait_slot", &RcclComm::wait_slot)
+      .def("wait_all_slots", &RcclComm::wait_all_slots)
+      .def("synchronize_comm_stream", &RcclComm::synchronize_comm_stream, py::call_guard<py::gil_scoped_release>())
+      .def("comm_stream_handle", [](const RcclComm& c) { return reinterpret_cast<uintptr_t>(c.comm_stream()); })
+      .def("group_start", &RcclComm::group_start)
+      .def("group_end", &RcclComm::group_end)
+      .def("num_async_ops", &RcclComm::num_async_ops)
+      .def("destroy", &RcclComm::destroy, py::call_guard<py::gil_scoped_release>())
+      .def("abort", &RcclComm::abort);
+
+  py::class_<Transport, std::shared_ptr<Transport>>(m, "Transport")
+      .def("native_average", &Transport::native_average)
+      .def("world", &Transport::world);
+  m.def("make_rccl_transport", &make_rccl_transport);
+  m.def("make_c10d_transport", &make_c10d_transport);
+  m.def("make_local_transport", &make_local_transport);
+
+  py::class_<BucketSpec>(m, "BucketSpec")
+      .def(py::init([](std::vector<int64_t> idx, std::vector<int64_t> offs, at::Tensor buffer) {
+             BucketSpec s;
+             s.param_indices = std::move(idx);
+             s.offsets = std::move(offs);
+             s.buffer = std::move(buffer);
+             return s;
+           }),
+           py::arg("param_indices"), py::arg("offsets"), py::arg("buffer"))
+      .def_readonly("param_indices", &BucketSpec::param_indices)
+      .def_readonly("offsets", &BucketSpec::offsets)
+      .def_readonly("buffer", &BucketSpec::buffer);
+
+  py::class_<Reducer, std::shared_ptr<Reducer>>(m, "Reducer")
+      .def(py::init([](std::vector<at::Tensor> params, std::vector<BucketSpec> buckets, std::shared_ptr<Transport> t,
+                       bool gradient_as_bucket_view, bool unpack_to_grads) {
+             ReducerOptions o;
+             o.gradient_as_bucket_view = gradient_as_bucket_view;
+             o.unpack_to_grads = unpack_to_grads;
+             return std::make_shared<Reducer>(std::move(params), std::move(buckets), std::move(t), o);
+           }),
+           py::arg("params"), py::arg("buckets"), py::arg("transport"), py::arg("gradient_as_bucket_view") = true,
+           py::arg("unpack_to_grads") = true)
+      .def("prepare_for_backward", &Reducer::prepare_for_backward, py::arg("sync") = true)
+      .def("armed", &Reducer::armed)
+      .def("ready_order", &Reducer::ready_order)
+      .def("num_buckets", &Reducer::num_buckets)
+      .def("num_backward_syncs", &Reducer::num_backward_syncs)
+      .def("num_bucket_launches", &Reducer::num_bucket_launches)
+      .def("num_pack_launches", &Reducer::num_pack_launches)
+      .def("broadcast_parameters", &Reducer::broadcast_parameters, py::arg("root") = 0,
+           py::call_guard<py::gil_scoped_release>())
+      .def("detach", &Reducer::detach);
+
+  init_ops(m);
+}

@@ -1,0 +1,256 @@
+#include "rccl_comm.h"
+
+#include <c10/hip/HIPStream.h>
+
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+
+namespace dpa {
+
+namespace {
+
+#define DPA_HIP_CHECK(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      std::ostringstream _os;                                                                \
+      _os << "HIP error " << hipGetErrorString(_e) << " at " << __FILE__ << ":" << __LINE__  \
+          << " in " #expr;                                                                   \
+      throw std::runtime_error(_os.str());                                                   \
+    }                                                                                        \
+  } while (0)
+
+#define DPA_NCCL_CHECK(expr)                                                                 \
+  do {                                                                                       \
+    ncclResult_t _r = (expr);                                                                \
+    if (_r != ncclSuccess && _r != ncclInProgress) {                                         \
+      std::ostringstream _os;                                                                \
+      _os << "RCCL error " << ncclGetErrorString(_r) << " at " << __FILE__ << ":" << __LINE__ \
+          << " in " #expr;                                                                   \
+      throw std::runtime_error(_os.str());                                                   \
+    }                                                                                        \
+  } while (0)
+
+hipStream_t current_stream(int device) {
+  return c10::hip::getCurrentHIPStream(static_cast<c10::DeviceIndex>(device)).stream();
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace
+
+ncclDataType_t to_nccl_dtype(at::ScalarType t) {
+  switch (t) {
+    case at::kFloat: return ncclFloat32;
+    case at::kDouble: return ncclFloat64;
+    case at::kHalf: return ncclFloat16;
+    case at::kBFloat16: return ncclBfloat16;
+    case at::kInt: return ncclInt32;
+    case at::kLong: return ncclInt64;
+    case at::kByte: return ncclUint8;
+    case at::kChar: return ncclInt8;
+    case at::kBool: return ncclUint8;
+    default: throw std::runtime_error(std::string("RcclComm: unsupported dtype ") + c10::toString(t));
+  }
+}
+
+std::string RcclComm::unique_id() {
+  ncclUniqueId id;
+  DPA_NCCL_CHECK(ncclGetUniqueId(&id));
+  return std::string(reinterpret_cast<const char*>(&id), sizeof(id));
+}
+
+RcclComm::RcclComm(const std::string& uid, int rank, int world, int device)
+    : rank_(rank), world_(world), device_(device) {
+  if (uid.size() != sizeof(ncclUniqueId)) throw std::runtime_error("RcclComm: bad unique id size");
+  ncclUniqueId id;
+  std::memcpy(&id, uid.data(), sizeof(id));
+  DPA_HIP_CHECK(hipSetDevice(device_));
+  DPA_NCCL_CHECK(ncclCommInitRank(&comm_, world_, id, rank_));
+  int lo = 0, hi = 0;
+  DPA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi is the numerically lowest = highest priority
+  DPA_HIP_CHECK(hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, hi));
+  DPA_HIP_CHECK(hipEventCreateWithFlags(&fence_event_, hipEventDisableTiming));
+  barrier_scratch_ = at::zeros({1}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, device_));
+}
+
+RcclComm::~RcclComm() {
+  try {
+    destroy();
+  } catch (...) {
+  }
+}
+
+void RcclComm::destroy() {
+  if (destroyed_) return;
+  destroyed_ = true;
+  DeviceGuard g(device_);
+  if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
+  if (comm_) {
+    (void)ncclCommFinalize(comm_);
+    (void)ncclCommDestroy(comm_);
+    comm_ = nullptr;
+  }
+  for (hipEvent_t e : slot_events_)
+    if (e) (void)hipEventDestroy(e);
+  slot_events_.clear();
+  if (fence_event_) (void)hipEventDestroy(fence_event_);
+  fence_event_ = nullptr;
+  if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
+  comm_stream_ = nullptr;
+  barrier_scratch_ = at::Tensor();
+}
+
+void RcclComm::abort() {
+  if (comm_) {
+    (void)ncclCommAbort(comm_);
+    comm_ = nullptr;
+  }
+}
+
+void RcclComm::check_tensor(const at::Tensor& t) const {
+  if (destroyed_ || !comm_) throw std::runtime_error("RcclComm: communicator already destroyed");
+  if (!t.is_cuda()) throw std::runtime_error("RcclComm: tensor must live on the GPU");
+  if (t.get_device() != device_) throw std::runtime_error("RcclComm: tensor is on a different device than the communicator");
+  if (!t.is_contiguous()) throw std::runtime_error("RcclComm: tensor must be contiguous");
+}
+
+void RcclComm::all_reduce(at::Tensor t, int op) {
+  check_tensor(t);
+  if (t.numel() == 0) return;
+  DeviceGuard g(device_);
+  DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
+                               static_cast<ncclRedOp_t>(op), comm_, current_stream(device_)));
+}
+
+void RcclComm::reduce(at::Tensor t, int root, int op) {
+  check_tensor(t);
+  if (t.numel() == 0) return;
+  DeviceGuard g(device_);
+  DPA_NCCL_CHECK(ncclReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
+                            static_cast<ncclRedOp_t>(op), root, comm_, current_stream(device_)));
+}
+
+void RcclComm::broadcast(at::Tensor t, int root) {
+  check_tensor(t);
+  if (t.numel() == 0) return;
+  DeviceGuard g(device_);
+  DPA_NCCL_CHECK(ncclBroadcast(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
+                               root, comm_, current_stream(device_)));
+}
+
+void RcclComm::gather(at::Tensor in, c10::optional<at::Tensor> out, int root) {
+  check_tensor(in);
+  void* recv = nullptr;
+  if (rank_ == root) {
+    if (!out.has_value()) throw std::runtime_error("RcclComm::gather: root needs an output tensor");
+    check_tensor(*out);
+    if (out->numel() != in.numel() * world_) throw std::runtime_error("RcclComm::gather: output must hold world * input elements");
+    recv = out->data_ptr();
+  }
+  if (in.numel() == 0) return;
+  DeviceGuard g(device_);
+  DPA_NCCL_CHECK(ncclGather(in.data_ptr(), recv, static_cast<size_t>(in.numel()), to_nccl_dtype(in.scalar_type()), root,
+                            comm_, current_stream(device_)));
+}
+
+void RcclComm::all_gather(at::Tensor in, at::Tensor out) {
+  check_tensor(in);
+  check_tensor(out);
+  if (out.numel() != in.numel() * world_) throw std::runtime_error("RcclComm::all_gather: output must hold world * input elements");
+  if (in.numel() == 0) return;
+  DeviceGuard g(device_);
+  DPA_NCCL_CHECK(ncclAllGather(in.data_ptr(), out.data_ptr(), static_cast<size_t>(in.numel()), to_nccl_dtype(in.scalar_type()),
+                               comm_, current_stream(device_)));
+}
+
+void RcclComm::reduce_scatter(at::Tensor in, at::Tensor out, int op) {
+  check_tensor(in);
+  check_tensor(out);
+  if (in.numel() != out.numel() * world_) throw std::runtime_error("RcclComm::reduce_scatter: input must hold world * output elements");
+  if (out.numel() == 0) return;
+  DeviceGuard g(device_);
+  DPA_NCCL_CHECK(ncclReduceScatter(in.data_ptr(), out.data_ptr(), static_cast<size_t>(out.numel()),
+                                   to_nccl_dtype(in.scalar_type()), static_cast<ncclRedOp_t>(op), comm_,
+                                   current_stream(device_)));
+}
+
+void RcclComm::barrier() {
+  if (destroyed_ || !comm_) throw std::runtime_error("RcclComm: communicator already destroyed");
+  DeviceGuard g(device_);
+  hipStream_t s = current_stream(device_);
+  DPA_NCCL_CHECK(ncclAllReduce(barrier_scratch_.data_ptr(), barrier_scratch_.data_ptr(), 1, ncclFloat32, ncclSum, comm_, s));
+  DPA_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+hipEvent_t& RcclComm::slot_event(int slot) {
+  if (slot < 0) throw std::runtime_error("RcclComm: negative slot");
+  if (static_cast<size_t>(slot) >= slot_events_.size()) {
+    slot_events_.resize(static_cast<size_t>(slot) + 1, nullptr);
+    slot_pending_.resize(static_cast<size_t>(slot) + 1, 0);
+  }
+  if (!slot_events_[static_cast<size_t>(slot)])
+    DPA_HIP_CHECK(hipEventCreateWithFlags(&slot_events_[static_cast<size_t>(slot)], hipEventDisableTiming));
+  return slot_events_[static_cast<size_t>(slot)];
+}
+
+void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
+  check_tensor(t);
+  DeviceGuard g(device_);
+  hipEvent_t& done = slot_event(slot);
+  // Fence: the bucket was filled by kernels queued on the current stream.
+  DPA_HIP_CHECK(hipEventRecord(fence_event_, current_stream(device_)));
+  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence_event_, 0));
+  if (t.numel() > 0)
+    DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
+                                 static_cast<ncclRedOp_t>(op), comm_, comm_stream_));
+  DPA_HIP_CHECK(hipEventRecord(done, comm_stream_));
+  slot_pending_[static_cast<size_t>(slot)] = 1;
+  ++n_async_;
+}
+
+void RcclComm::broadcast_async(at::Tensor t, int root, int slot) {
+  check_tensor(t);
+  DeviceGuard g(device_);
+  hipEvent_t& done = slot_event(slot);
+  DPA_HIP_CHECK(hipEventRecord(fence_event_, current_stream(device_)));
+  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence_event_, 0));
+  if (t.numel() > 0)
+    DPA_NCCL_CHECK(ncclBroadcast(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
+                                 root, comm_, comm_stream_));
+  DPA_HIP_CHECK(hipEventRecord(done, comm_stream_));
+  slot_pending_[static_cast<size_t>(slot)] = 1;
+  ++n_async_;
+}
+
+void RcclComm::wait_slot(int slot) {
+  if (slot < 0 || static_cast<size_t>(slot) >= slot_events_.size() || !slot_pending_[static_cast<size_t>(slot)]) return;
+  DeviceGuard g(device_);
+  DPA_HIP_CHECK(hipStreamWaitEvent(current_stream(device_), slot_events_[static_cast<size_t>(slot)], 0));
+  slot_pending_[static_cast<size_t>(slot)] = 0;
+}
+
+void RcclComm::wait_all_slots() {
+  for (size_t i = 0; i < slot_events_.size(); ++i) wait_slot(static_cast<int>(i));
+}
+
+void RcclComm::synchronize_comm_stream() {
+  DeviceGuard g(device_);
+  if (comm_stream_) DPA_HIP_CHECK(hipStreamSynchronize(comm_stream_));
+}
+
+void RcclComm::group_start() { DPA_NCCL_CHECK(ncclGroupStart()); }
+void RcclComm::group_end() { DPA_NCCL_CHECK(ncclGroupEnd()); }
+
+}  // namespace dpa

@@ -1,0 +1,83 @@
+// RCCL communicator bound to one GPU, driven directly (no c10d ProcessGroup).
+//
+// This is the GPU data plane behind every collective of the `distributed` facade -- the
+// role ProcessGroupNCCL plays for the reference (reference distributed.py:62-66, 119-177):
+//   * the ncclUniqueId travels through our TCP store, the communicator is created eagerly;
+//   * a dedicated high-priority HIP stream carries the gradient-bucket all-reduces so they
+//     overlap the backward kernels running on torch's current stream; ordering between the
+//     two streams is expressed with hipEvents only (no host synchronisation);
+//   * metric-sized collectives (reduce / gather / barrier) are issued on the current stream,
+//     where a dependency on the preceding kernels already exists, so they cost no fences;
+//   * gather uses RCCL's native ncclGather instead of grouped send/recv.
+// xGMI peer-to-peer is left enabled (the reference disables P2P, distributed.py:47).
+#pragma once
+
+#include <ATen/ATen.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace dpa {
+
+class RcclComm {
+ public:
+  static std::string unique_id();  // 128 raw bytes from ncclGetUniqueId
+
+  RcclComm(const std::string& uid, int rank, int world, int device);
+  ~RcclComm();
+  RcclComm(const RcclComm&) = delete;
+  RcclComm& operator=(const RcclComm&) = delete;
+
+  int rank() const { return rank_; }
+  int world() const { return world_; }
+  int device() const { return device_; }
+
+  // ---- collectives on torch's *current* stream (stream-ordered with the caller's kernels)
+  void all_reduce(at::Tensor t, int op);
+  void reduce(at::Tensor t, int root, int op);
+  void broadcast(at::Tensor t, int root);
+  void gather(at::Tensor in, c10::optional<at::Tensor> out, int root);
+  void all_gather(at::Tensor in, at::Tensor out);
+  void reduce_scatter(at::Tensor in, at::Tensor out, int op);
+  void barrier();  // 1-element all-reduce, then the host waits for it
+
+  // ---- collectives on the dedicated communication stream (gradient buckets)
+  // The comm stream first waits for everything queued so far on the current stream, then
+  // runs the all-reduce; `slot` names the completion event to wait on later.
+  void all_reduce_async(at::Tensor t, int op, int slot);
+  void broadcast_async(at::Tensor t, int root, int slot);
+  void wait_slot(int slot);         // current stream waits for slot's completion event
+  void wait_all_slots();            // ... for every slot used since the last call
+  void synchronize_comm_stream();   // host waits (debug / teardown)
+  hipStream_t comm_stream() const { return comm_stream_; }
+
+  void group_start();
+  void group_end();
+
+  void destroy();  // ncclCommFinalize + ncclCommDestroy; idempotent
+  void abort();    // ncclCommAbort (used on timeout paths)
+
+  // Timing of the last bucket collectives, for the bus-bandwidth report.
+  int64_t num_async_ops() const { return n_async_; }
+
+ private:
+  hipEvent_t& slot_event(int slot);
+  void check_tensor(const at::Tensor& t) const;
+
+  ncclComm_t comm_ = nullptr;
+  int rank_, world_, device_;
+  hipStream_t comm_stream_ = nullptr;
+  hipEvent_t fence_event_ = nullptr;
+  std::vector<hipEvent_t> slot_events_;
+  std::vector<char> slot_pending_;
+  at::Tensor barrier_scratch_;
+  int64_t n_async_ = 0;
+  bool destroyed_ = false;
+};
+
+ncclDataType_t to_nccl_dtype(at::ScalarType t);
+
+}  // namespace dpa

@@ -1,0 +1,129 @@
+// Device-side helpers shared by the gfx950 kernels: 16-bit float conversion, 16-byte
+// vector access, 64-lane wave reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dpa {
+namespace kernels {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+struct F32 {
+  using T = float;
+  static constexpr int kVec = 4;  // elements per 16-byte access
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+struct BF16 {
+  using T = u16;
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ float to_f32(u16 v) {
+    return __uint_as_float(static_cast<unsigned>(v) << 16);
+  }
+  static __device__ __forceinline__ u16 from_f32(float v) {
+    __bf16 b = static_cast<__bf16>(v);  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(u16, b);
+  }
+};
+struct F16 {
+  using T = u16;
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ float to_f32(u16 v) {
+    return static_cast<float>(__builtin_bit_cast(_Float16, v));
+  }
+  static __device__ __forceinline__ u16 from_f32(float v) {
+    return __builtin_bit_cast(u16, static_cast<_Float16>(v));
+  }
+};
+
+// Loads/stores N consecutive elements as fp32.  `aligned16` selects 16-byte accesses.
+template <typename TR, int N>
+__device__ __forceinline__ void load_as_f32(const typename TR::T* p, float (&out)[N]) {
+  static_assert(N % TR::kVec == 0, "N must be a multiple of the 16-byte vector width");
+  if constexpr (TR::kVec == 4) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[4 * i + j] = v[j];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      u16x8 v = *reinterpret_cast<const u16x8*>(p + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[8 * i + j] = TR::to_f32(v[j]);
+    }
+  }
+}
+
+template <typename TR, int N>
+__device__ __forceinline__ void store_from_f32(typename TR::T* p, const float (&in)[N]) {
+  static_assert(N % TR::kVec == 0, "N must be a multiple of the 16-byte vector width");
+  if constexpr (TR::kVec == 4) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = in[4 * i + j];
+      *reinterpret_cast<f32x4*>(p + 4 * i) = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      u16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = TR::from_f32(in[8 * i + j]);
+      *reinterpret_cast<u16x8*>(p + 8 * i) = v;
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Sum across a workgroup of NWAVES waves; every thread gets the result.  `scratch` holds
+// at least NWAVES floats of LDS and may be reused after the call returns.
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  if constexpr (NWAVES == 1) return v;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWAVES; ++i) r += scratch[i];
+  return r;
+}
+
+template <typename F>
+inline void dispatch_dtype(int dt, F&& f) {
+  switch (dt) {
+    case 0: f(F32{}); break;
+    case 1: f(BF16{}); break;
+    default: f(F16{}); break;
+  }
+}
+
+}  // namespace kernels
+}  // namespace dpa

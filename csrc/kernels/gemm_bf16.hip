@@ -1,0 +1,215 @@
+// bf16 matrix products on the gfx950 matrix cores (fp32 accumulate), fused bias /
+// activation epilogue, all three operand layouts a linear layer needs.
+//
+// Serves the same nn.Linear forward / backward products as gemm_f32.hip
+// (reference min_DDP.py:41-49, 98, 103) for the bf16 configurations (wide MLP, GPT-2).
+//   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 =
+//     4x4 tiles of v_mfma_f32_16x16x32_bf16 (64 accumulator registers);
+//   * K is consumed 64 at a time through double-buffered LDS (2 x 32 KiB); the global loads
+//     of step k+1 are in flight during the MFMAs of step k and land in the other buffer
+//     after them, one barrier per step;
+//   * an operand with the contraction index contiguous in memory is kept as [row][64 k]
+//     (128-byte rows, 16-byte chunks XOR-swizzled by (row>>1)&7): one ds_read_b128 is one
+//     whole MFMA fragment (8 consecutive k of one row);
+//   * an operand stored [k][row] (weights in the input-gradient product, both operands of
+//     the weight-gradient product) is kept as [64 k][128 rows] and read with the hardware
+//     transposing load ds_read_b64_tr_b16: a 16-lane group fetches a 4(k) x 16(row) block
+//     and each lane receives its row's four k values, so no transpose pass over memory and
+//     no scattered LDS writes are needed.  16-byte chunks are XOR-swizzled by
+//     2*((k&3) + 4*((k>>3)&1)) so that the eight 4-row blocks a 32-lane half touches fall
+//     on disjoint bank ranges;
+//   * XCD-aware workgroup remap as in the fp32 kernel.
+#include <type_traits>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace dpa {
+namespace kernels {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand per stage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == kActRelu) return v > 0.f ? v : 0.f;
+  if (act == kActGelu) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  return v;
+}
+
+// Byte offset of 16-byte chunk c (8 k-values) of `row` in the swizzled [128][64] image.
+__device__ __forceinline__ int kmajor_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+// Byte offset of 16-byte chunk c (8 rows) of contraction index k in the swizzled [64][128] image.
+__device__ __forceinline__ int rmajor_off(int k, int c) { return k * 256 + ((c ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)))) << 4); }
+
+template <bool KMAJOR>
+__device__ __forceinline__ void load_tile(const u16* __restrict__ base, long long ld, long long r0, long long R, long long k0,
+                                          long long K, u32x4 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = threadIdx.x + i * kThreads;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (KMAJOR) {
+      const long long row = r0 + (id >> 3), k = k0 + ((id & 7) << 3);
+      if (row < R && k < K) v = *reinterpret_cast<const u32x4*>(base + row * ld + k);
+    } else {
+      const long long k = k0 + (id >> 4), row = r0 + ((id & 15) << 3);
+      if (k < K && row < R) v = *reinterpret_cast<const u32x4*>(base + k * ld + row);
+    }
+    regs[i] = v;
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void store_tile(char* lds, const u32x4 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = threadIdx.x + i * kThreads;
+    const int off = KMAJOR ? kmajor_off(id >> 3, id & 7) : rmajor_off(id >> 4, id & 15);
+    *reinterpret_cast<u32x4*>(lds + off) = regs[i];
+  }
+}
+
+// MFMA fragment of the 16-row tile starting at tile_row0 for k-substep kk (32 k-values):
+// lane l holds row l&15, k = 32*kk + 8*(l>>4) + 0..7.
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int tile_row0, int kk, int lane) {
+  if (KMAJOR) {
+    return *reinterpret_cast<const bf16x8*>(lds + kmajor_off(tile_row0 + (lane & 15), 4 * kk + (lane >> 4)));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int k1 = 32 * kk + 8 * g + q;
+    const int c = (tile_row0 >> 3) + (pp >> 1);
+    const int sub = (pp & 1) << 3;
+    using lds_ptr = __attribute__((address_space(3))) s16x4*;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + rmajor_off(k1, c) + sub));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + rmajor_off(k1 + 4, c) + sub));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem_bf16[];
+
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+  const long long m0 = static_cast<long long>(tm) * BM, n0 = static_cast<long long>(tn) * BN;
+
+  const u16* A = static_cast<const u16*>(p.A);
+  const u16* B = static_cast<const u16*>(p.B);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rb[4];
+  const long long nk = (p.K + BK - 1) / BK;
+  load_tile<A_KMAJOR>(A, p.lda, m0, p.M, 0, p.K, ra);
+  load_tile<B_KMAJOR>(B, p.ldb, n0, p.N, 0, p.K, rb);
+  store_tile<A_KMAJOR>(smem_bf16, ra);
+  store_tile<B_KMAJOR>(smem_bf16 + kTileBytes, rb);
+  __syncthreads();
+
+  int cur = 0;
+  for (long long kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_tile<A_KMAJOR>(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, ra);
+      load_tile<B_KMAJOR>(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, rb);
+    }
+    const char* as = smem_bf16 + cur * 2 * kTileBytes;
+    const char* bs = as + kTileBytes;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KMAJOR>(as, wm + 16 * i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR>(bs, wn + 16 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* an = smem_bf16 + (cur ^ 1) * 2 * kTileBytes;
+      store_tile<A_KMAJOR>(an, ra);
+      store_tile<B_KMAJOR>(an + kTileBytes, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // Epilogue.  Register e of lane l holds C[row = 4*(l>>4) + e][col = l&15] of its 16x16 tile.
+  u16* C = static_cast<u16*>(p.C);
+  u16* P = static_cast<u16*>(p.pre_act);
+  const u16* bias = static_cast<const u16*>(p.bias);
+  const int col_in = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long col = n0 + wn + 16 * j + col_in;
+    if (col >= p.N) continue;
+    const float bv = bias ? BF16::to_f32(bias[col]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long row = m0 + wm + 16 * i + 4 * rq + e;
+        if (row >= p.M) continue;
+        float v = p.alpha * acc[i][j][e] + bv;
+        if (p.beta != 0.f) v += p.beta * BF16::to_f32(C[row * p.ldc + col]);
+        if (P) P[row * p.ldc + col] = BF16::from_f32(v);
+        C[row * p.ldc + col] = BF16::from_f32(act_fn(v, p.act));
+      }
+    }
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+bool gemm_bf16_supported(const GemmArgs& a) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
+  // 16-byte global loads: contiguous extents and leading dimensions in multiples of 8 elements.
+  if (a.lda % 8 || a.ldb % 8) return false;
+  if (a.a_kmajor ? (a.K % 8) : (a.M % 8)) return false;
+  if (a.b_kmajor ? (a.K % 8) : (a.N % 8)) return false;
+  if (a.A && !aligned16(a.A)) return false;
+  if (a.B && !aligned16(a.B)) return false;
+  const long long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  return tiles < (1ll << 31);
+}
+
+void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
+  const int tiles_m = static_cast<int>((a.M + BM - 1) / BM), tiles_n = static_cast<int>((a.N + BN - 1) / BN);
+  const dim3 grid(static_cast<unsigned>(tiles_m) * static_cast<unsigned>(tiles_n));
+  const size_t lds = 4 * kTileBytes;
+  auto go = [&](auto ak, auto bk) {
+    constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
+    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
+  };
+  if (a.a_kmajor && a.b_kmajor) go(std::true_type{}, std::true_type{});
+  else if (a.a_kmajor && !a.b_kmajor) go(std::true_type{}, std::false_type{});
+  else if (!a.a_kmajor && a.b_kmajor) go(std::false_type{}, std::true_type{});
+  else go(std::false_type{}, std::false_type{});
+}
+
+}  // namespace kernels
+}  // namespace dpa

@@ -1,0 +1,140 @@
+// Host-callable launchers of the gfx950 HIP kernels.  Raw pointers + hipStream_t only, so
+// the kernel translation units never see a torch header (they compile in seconds) and the
+// launchers can be captured into a hipGraph: none of them allocates, copies or synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dpa {
+namespace kernels {
+
+enum DType : int { kF32 = 0, kBF16 = 1, kF16 = 2 };
+
+inline int dtype_size(int dt) { return dt == kF32 ? 4 : 2; }
+
+// ------------------------------------------------------------------ bucket pack / unpack
+// Multi-tensor "dst[i] = cast(src[i] * scale)".  One launch covers up to kMaxTensors
+// tensors; tensor t owns blocks [block_start[t], block_start[t+1]).
+struct CopyTable {
+  static constexpr int kMaxTensors = 32;
+  static constexpr int kChunk = 8192;  // elements per workgroup
+  const void* src[kMaxTensors];
+  void* dst[kMaxTensors];
+  long long numel[kMaxTensors];
+  int block_start[kMaxTensors + 1];
+  int n;
+};
+void launch_multi_copy_scale(const CopyTable& t, int src_dtype, int dst_dtype, float scale,
+                             hipStream_t stream);
+void launch_scale_inplace(void* p, long long n, int dtype, float scale, hipStream_t stream);
+
+// ------------------------------------------------------------------ fused AdamW
+// Hyper-parameters live in device memory so a captured graph replays with the current
+// learning rate and step: [lr, beta1, beta2, eps, weight_decay, step(as int bits),
+// 1-beta1^step, sqrt(1-beta2^step)].
+struct AdamWTable {
+  static constexpr int kMaxTensors = 24;
+  static constexpr int kChunk = 4096;
+  void* param[kMaxTensors];
+  const void* grad[kMaxTensors];
+  float* exp_avg[kMaxTensors];
+  float* exp_avg_sq[kMaxTensors];
+  float* master[kMaxTensors];  // fp32 master copy for 16-bit params, else nullptr
+  long long numel[kMaxTensors];
+  int block_start[kMaxTensors + 1];
+  int n;
+};
+constexpr int kAdamWHparamFloats = 8;
+void launch_adamw_tick(float* hparams, hipStream_t stream);
+void launch_adamw(const AdamWTable& t, int param_dtype, int grad_dtype, const float* hparams,
+                  const float* grad_scale /*device scalar or nullptr*/, hipStream_t stream);
+// Sum of squares of up to kMaxTensors tensors accumulated into out[0] (fp32, pre-zeroed),
+// and the clip coefficient min(1, max_norm / (sqrt(out[0]) + 1e-6)) written by the finisher.
+void launch_sumsq(const CopyTable& t, int dtype, float* out, hipStream_t stream);
+void launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out,
+                      hipStream_t stream);
+
+// ------------------------------------------------------------------ softmax cross-entropy
+// logits: [N, ld] with the first C columns valid.  Per row: loss (0 for ignored rows),
+// log-sum-exp, and a correct flag (argmax == target, lowest index wins ties).
+void launch_xent_fwd(const void* logits, int dtype, const long long* targets, long long N,
+                     long long C, long long ld, long long ignore_index, float* row_loss,
+                     float* row_lse, unsigned char* correct, hipStream_t stream);
+// metrics[0]=sum of row losses, [1]=correct count, [2]=non-ignored rows, [3]=mean loss.
+void launch_xent_reduce(const float* row_loss, const unsigned char* correct,
+                        const long long* targets, long long N, long long ignore_index,
+                        float* metrics, hipStream_t stream);
+// dlogits = (softmax - onehot) * grad_out[0] * (mean ? 1/metrics[2] : 1); padded columns
+// [C, ld) are written as zero.  dlogits may alias logits.
+void launch_xent_bwd(const void* logits, int dtype, const long long* targets, const float* row_lse,
+                     const float* grad_out, const float* metrics, int mean, long long N,
+                     long long C, long long ld, long long ignore_index, void* dlogits,
+                     hipStream_t stream);
+
+// ------------------------------------------------------------------ dense layers
+enum Act : int { kActNone = 0, kActRelu = 1, kActGelu = 2 };
+
+// C[M,N] = act(A * B^T + bias) style products on the matrix cores.  Layout flags say which
+// dimension of each operand is contiguous:  a_kmajor: A is [M,K] row-major (K contiguous),
+// else A is stored [K,M];  b_kmajor: B is [N,K] row-major, else B is stored [K,N].
+//   forward  y  = x W^T + b : A=x [M,K] kmajor, B=W [N,K] kmajor
+//   grad-in  dx = dy W      : A=dy [M,N'] kmajor, B=W stored [K'=N', N=K_in]  (not kmajor)
+//   grad-w   dW = dy^T x    : A=dy stored [K'=M, M'=N] (not kmajor), B=x stored [K'=M, N'=K_in]
+// pre_act (optional) receives A*B^T + bias before the activation (needed by GELU backward).
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* bias;  // [N] or nullptr
+  void* pre_act;     // [M,N] or nullptr
+  long long M, N, K;
+  long long lda, ldb, ldc;
+  int a_kmajor, b_kmajor;
+  int act;
+  float alpha;
+  float beta;        // C = alpha*acc + beta*C_old (beta != 0 only with act == none, no bias)
+};
+bool gemm_f32_supported(const GemmArgs& a);
+void launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
+bool gemm_bf16_supported(const GemmArgs& a);
+void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
+
+// Degenerate shapes of the reference MLP (in_dim = 1, n_classes = 4), fp32 or bf16 storage:
+//   y[M,N] = act(x[M,1] * w[N,1]^T + b)                     (K = 1 outer product)
+void launch_outer_bias_act(const void* x, const void* w, const void* bias, void* y, long long M,
+                           long long N, int dtype, int act, hipStream_t stream);
+//   y[M,N] = x[M,K] W[N,K]^T + b  with N <= 16               (skinny output)
+void launch_skinny_n(const void* x, const void* w, const void* bias, void* y, long long M,
+                     long long N, long long K, int dtype, hipStream_t stream);
+//   dx[M,K] = dy[M,N] W[N,K]  with N <= 16
+void launch_skinny_n_dgrad(const void* dy, const void* w, void* dx, long long M, long long N,
+                           long long K, int dtype, hipStream_t stream);
+//   dW[N,K] = dy[M,N]^T x[M,K] with N <= 16 (split over M, fp32 partials in `workspace`),
+//   db[N] = colsum(dy).  workspace: at least skinny_wgrad_workspace(M,N,K) floats.
+long long skinny_wgrad_workspace(long long M, long long N, long long K);
+void launch_skinny_n_wgrad(const void* dy, const void* x, void* dW, void* db, float* workspace,
+                           long long M, long long N, long long K, int dtype, hipStream_t stream);
+//   dw[N] = sum_m dy[m,n] * x[m] ; db[N] = sum_m dy[m,n]      (K = 1 weight grad)
+long long colreduce_workspace(long long M, long long N);
+void launch_outer_wgrad(const void* dy, const void* x, void* dw, void* db, float* workspace,
+                        long long M, long long N, int dtype, hipStream_t stream);
+//   db[N] = colsum(dy[M,N])  (also used by the large-GEMM path)
+void launch_colsum(const void* dy, void* db, float* workspace, long long M, long long N, int dtype,
+                   hipStream_t stream);
+//   g = dy * act'(saved)  (+ db = colsum(g)); saved = y for ReLU, pre-activation for GELU.
+void launch_act_bwd(const void* dy, const void* saved, void* g, void* db, float* workspace,
+                    long long M, long long N, int dtype, int act, hipStream_t stream);
+
+// ------------------------------------------------------------------ layer norm
+void launch_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
+                          float* rstd, long long rows, long long cols, float eps, int dtype,
+                          hipStream_t stream);
+long long layernorm_bwd_workspace(long long rows, long long cols);
+void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
+                          const float* rstd, void* dx, void* dgamma, void* dbeta, float* workspace,
+                          long long rows, long long cols, int dtype, hipStream_t stream);
+
+}  // namespace kernels
+}  // namespace dpa

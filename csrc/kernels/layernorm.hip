@@ -1,0 +1,233 @@
+// Layer normalisation forward / backward for gfx950 (used by the GPT-2 configuration).
+//
+// One 64-lane wave owns one row and keeps it in registers: the row is read from HBM once,
+// mean and variance are two wave-shuffle reductions, and the result is written once
+// (16-byte accesses per lane).  The backward pass does the same per row for dx, and because
+// a lane always owns the same columns it accumulates its share of dgamma / dbeta in
+// registers across all rows its workgroup visits; workgroups then emit one partial row
+// each and a second small kernel sums them (deterministic, no float atomics).
+#include <type_traits>
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace dpa {
+namespace kernels {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxBlocks = 512;
+
+// MAXV = vectors (of TR::kVec elements) per lane; supports cols <= 64 * kVec * MAXV.
+template <typename TR, int MAXV>
+__global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename TR::T* __restrict__ x,
+                                                                 const typename TR::T* __restrict__ gamma,
+                                                                 const typename TR::T* __restrict__ beta,
+                                                                 typename TR::T* __restrict__ y, float* __restrict__ mean_out,
+                                                                 float* __restrict__ rstd_out, long long rows, int cols,
+                                                                 float eps) {
+  constexpr int V = TR::kVec;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nvec = cols / V;
+  const float inv_n = 1.f / static_cast<float>(cols);
+  for (long long row = static_cast<long long>(blockIdx.x) * kWaves + wid; row < rows; row += static_cast<long long>(gridDim.x) * kWaves) {
+    const typename TR::T* xr = x + row * cols;
+    float v[MAXV][V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        load_as_f32<TR, V>(xr + vi * V, v[i]);
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += v[i][j];
+      }
+    }
+    const float mean = wave_sum(s) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (lane + 64 * i < nvec) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float d = v[i][j] - mean;
+          sq += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_n + eps);
+    if (lane == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    typename TR::T* yr = y + row * cols;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float g[V], b[V], o[V];
+        load_as_f32<TR, V>(gamma + vi * V, g);
+        load_as_f32<TR, V>(beta + vi * V, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+        store_from_f32<TR, V>(yr + vi * V, o);
+      }
+    }
+  }
+}
+
+template <typename TR, int MAXV>
+__global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename TR::T* __restrict__ dy,
+                                                                 const typename TR::T* __restrict__ x,
+                                                                 const typename TR::T* __restrict__ gamma,
+                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                 typename TR::T* __restrict__ dx, float* __restrict__ partial,
+                                                                 long long rows, int cols) {
+  constexpr int V = TR::kVec;
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [kWaves][2][cols]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nvec = cols / V;
+  const float inv_n = 1.f / static_cast<float>(cols);
+
+  float gam[MAXV][V], dg[MAXV][V], db[MAXV][V];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nvec) load_as_f32<TR, V>(gamma + vi * V, gam[i]);
+#pragma unroll
+    for (int j = 0; j < V; ++j) dg[i][j] = db[i][j] = 0.f;
+  }
+
+  for (long long row = static_cast<long long>(blockIdx.x) * kWaves + wid; row < rows; row += static_cast<long long>(gridDim.x) * kWaves) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[MAXV][V], gy[MAXV][V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        load_as_f32<TR, V>(x + row * cols + vi * V, xh[i]);
+        load_as_f32<TR, V>(dy + row * cols + vi * V, gy[i]);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          xh[i][j] = (xh[i][j] - mean) * rstd;
+          dg[i][j] += gy[i][j] * xh[i][j];
+          db[i][j] += gy[i][j];
+          gy[i][j] *= gam[i][j];
+          s1 += gy[i][j];
+          s2 += gy[i][j] * xh[i][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = rstd * (gy[i][j] - s1 - xh[i][j] * s2);
+        store_from_f32<TR, V>(dx + row * cols + vi * V, o);
+      }
+    }
+  }
+
+  // Combine the workgroup's waves through LDS, then one partial row per workgroup.
+  float* sg = ln_smem + static_cast<size_t>(wid) * 2 * cols;
+  float* sb = sg + cols;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        sg[vi * V + j] = dg[i][j];
+        sb[vi * V + j] = db[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  float* out = partial + static_cast<size_t>(blockIdx.x) * 2 * cols;
+  for (int c = threadIdx.x; c < 2 * cols; c += kThreads) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += ln_smem[static_cast<size_t>(w) * 2 * cols + c];
+    out[c] = s;
+  }
+}
+
+template <typename TR>
+__global__ __launch_bounds__(kThreads) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, typename TR::T* __restrict__ dgamma,
+                                                                        typename TR::T* __restrict__ dbeta, int cols, int nblocks) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= 2 * cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[static_cast<size_t>(b) * 2 * cols + c];
+  if (c < cols) dgamma[c] = TR::from_f32(s);
+  else dbeta[c - cols] = TR::from_f32(s);
+}
+
+int pick_blocks(long long rows) {
+  long long b = (rows + kWaves - 1) / kWaves;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+template <typename F>
+bool dispatch_maxv(int need, int limit, F&& f) {
+  if (need > limit) return false;
+  if (need <= 1) f(std::integral_constant<int, 1>{});
+  else if (need <= 2) f(std::integral_constant<int, 2>{});
+  else if (need <= 4) f(std::integral_constant<int, 4>{});
+  else f(std::integral_constant<int, 8>{});
+  return true;
+}
+
+}  // namespace
+
+void launch_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, long long rows,
+                          long long cols, float eps, int dtype, hipStream_t stream) {
+  if (rows <= 0) return;
+  dispatch_dtype(dtype, [&](auto tr) {
+    using TR = decltype(tr);
+    using T = typename TR::T;
+    const int need = static_cast<int>((cols / TR::kVec + 63) / 64);
+    long long blocks = (rows + kWaves - 1) / kWaves;
+    if (blocks > 4096) blocks = 4096;
+    dispatch_maxv(need, 8, [&](auto mv) {
+      constexpr int MAXV = decltype(mv)::value;
+      hipLaunchKernelGGL((layernorm_fwd_kernel<TR, MAXV>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream,
+                         static_cast<const T*>(x), static_cast<const T*>(gamma), static_cast<const T*>(beta), static_cast<T*>(y), mean,
+                         rstd, rows, static_cast<int>(cols), eps);
+    });
+  });
+}
+
+long long layernorm_bwd_workspace(long long rows, long long cols) { return 2 * cols * pick_blocks(rows); }
+
+void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, void* dx, void* dgamma,
+                          void* dbeta, float* workspace, long long rows, long long cols, int dtype, hipStream_t stream) {
+  if (rows <= 0) return;
+  dispatch_dtype(dtype, [&](auto tr) {
+    using TR = decltype(tr);
+    using T = typename TR::T;
+    const int need = static_cast<int>((cols / TR::kVec + 63) / 64);
+    const int blocks = pick_blocks(rows);
+    const size_t lds = static_cast<size_t>(kWaves) * 2 * cols * sizeof(float);
+    dispatch_maxv(need, 4, [&](auto mv) {
+      constexpr int MAXV = decltype(mv)::value;
+      hipLaunchKernelGGL((layernorm_bwd_kernel<TR, (MAXV > 4 ? 4 : MAXV)>), dim3(blocks), dim3(kThreads), lds, stream,
+                         static_cast<const T*>(dy), static_cast<const T*>(x), static_cast<const T*>(gamma), mean, rstd, static_cast<T*>(dx),
+                         workspace, rows, static_cast<int>(cols));
+    });
+    hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((2 * cols + kThreads - 1) / kThreads)), dim3(kThreads),
+                       0, stream, workspace, static_cast<T*>(dgamma), static_cast<T*>(dbeta), static_cast<int>(cols), blocks);
+  });
+}
+
+}  // namespace kernels
+}  // namespace dpa

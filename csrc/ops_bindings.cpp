@@ -1,0 +1,480 @@
+// Tensor-level entry points of the HIP kernels.  Every function validates shapes, dtypes,
+// devices and contiguity on the host before a launch, allocates outputs through torch's
+// caching allocator, and launches on torch's current HIP stream.
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <tuple>
+
+#include "kernels/kernels.h"
+
+namespace py = pybind11;
+using namespace dpa;
+using at::Tensor;
+
+namespace {
+
+int kdtype(const Tensor& t) {
+  switch (t.scalar_type()) {
+    case at::kFloat: return kernels::kF32;
+    case at::kBFloat16: return kernels::kBF16;
+    case at::kHalf: return kernels::kF16;
+    default: TORCH_CHECK(false, "unsupported dtype ", t.scalar_type(), " (float32 / bfloat16 / float16 expected)");
+  }
+}
+
+hipStream_t stream_of(const Tensor& t) {
+  return c10::hip::getCurrentHIPStream(static_cast<c10::DeviceIndex>(t.get_device())).stream();
+}
+
+void check_gpu(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.defined(), name, " is undefined");
+  TORCH_CHECK(t.is_cuda(), name, " must be a GPU tensor");
+  TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+}
+
+struct DevGuard {
+  int prev = -1;
+  explicit DevGuard(const Tensor& t) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != t.get_device()) {
+      prev = cur;
+      (void)hipSetDevice(t.get_device());
+    }
+  }
+  ~DevGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// ------------------------------------------------------------------ pack / scale
+void multi_copy_scale(const std::vector<Tensor>& srcs, const std::vector<Tensor>& dsts, double scale) {
+  TORCH_CHECK(srcs.size() == dsts.size(), "multi_copy_scale: list sizes differ");
+  if (srcs.empty()) return;
+  DevGuard g(srcs[0]);
+  hipStream_t stream = stream_of(srcs[0]);
+  for (int sd = 0; sd < 3; ++sd)
+    for (int dd = 0; dd < 3; ++dd) {
+      kernels::CopyTable tab;
+      tab.n = 0;
+      tab.block_start[0] = 0;
+      auto flush = [&]() {
+        if (tab.n > 0) kernels::launch_multi_copy_scale(tab, sd, dd, static_cast<float>(scale), stream);
+        tab.n = 0;
+        tab.block_start[0] = 0;
+      };
+      for (size_t i = 0; i < srcs.size(); ++i) {
+        check_gpu(srcs[i], "src");
+        check_gpu(dsts[i], "dst");
+        TORCH_CHECK(srcs[i].numel() == dsts[i].numel(), "multi_copy_scale: element counts differ at index ", i);
+        TORCH_CHECK(srcs[i].get_device() == dsts[i].get_device(), "multi_copy_scale: device mismatch at index ", i);
+        if (kdtype(srcs[i]) != sd || kdtype(dsts[i]) != dd || srcs[i].numel() == 0) continue;
+        if (tab.n == kernels::CopyTable::kMaxTensors) flush();
+        const int k = tab.n;
+        tab.src[k] = srcs[i].data_ptr();
+        tab.dst[k] = dsts[i].data_ptr();
+        tab.numel[k] = srcs[i].numel();
+        tab.block_start[k + 1] = tab.block_start[k] + static_cast<int>((srcs[i].numel() + kernels::CopyTable::kChunk - 1) / kernels::CopyTable::kChunk);
+        tab.n = k + 1;
+      }
+      flush();
+    }
+}
+
+void scale_inplace(Tensor t, double scale) {
+  check_gpu(t, "tensor");
+  DevGuard g(t);
+  kernels::launch_scale_inplace(t.data_ptr(), t.numel(), kdtype(t), static_cast<float>(scale), stream_of(t));
+}
+
+// ------------------------------------------------------------------ AdamW
+void adamw_tick(Tensor hparams) {
+  check_gpu(hparams, "hparams");
+  TORCH_CHECK(hparams.scalar_type() == at::kFloat && hparams.numel() >= kernels::kAdamWHparamFloats, "hparams: float32[8] expected");
+  DevGuard g(hparams);
+  kernels::launch_adamw_tick(hparams.data_ptr<float>(), stream_of(hparams));
+}
+
+void adamw_step(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
+                const std::vector<Tensor>& exp_avg_sqs, const std::vector<c10::optional<Tensor>>& masters, Tensor hparams,
+                c10::optional<Tensor> grad_scale) {
+  const size_t n = params.size();
+  TORCH_CHECK(grads.size() == n && exp_avgs.size() == n && exp_avg_sqs.size() == n && masters.size() == n,
+              "adamw_step: list sizes differ");
+  if (n == 0) return;
+  check_gpu(hparams, "hparams");
+  TORCH_CHECK(hparams.scalar_type() == at::kFloat && hparams.numel() >= kernels::kAdamWHparamFloats, "hparams: float32[8] expected");
+  const float* gs = nullptr;
+  if (grad_scale.has_value() && grad_scale->defined()) {
+    check_gpu(*grad_scale, "grad_scale");
+    TORCH_CHECK(grad_scale->scalar_type() == at::kFloat && grad_scale->numel() >= 1, "grad_scale: float32 scalar expected");
+    gs = grad_scale->data_ptr<float>();
+  }
+  DevGuard g(params[0]);
+  hipStream_t stream = stream_of(params[0]);
+  for (int pd = 0; pd < 3; ++pd)
+    for (int gd = 0; gd < 3; ++gd) {
+      kernels::AdamWTable tab;
+      tab.n = 0;
+      tab.block_start[0] = 0;
+      auto flush = [&]() {
+        if (tab.n > 0) kernels::launch_adamw(tab, pd, gd, hparams.data_ptr<float>(), gs, stream);
+        tab.n = 0;
+        tab.block_start[0] = 0;
+      };
+      for (size_t i = 0; i < n; ++i) {
+        check_gpu(params[i], "param");
+        check_gpu(grads[i], "grad");
+        check_gpu(exp_avgs[i], "exp_avg");
+        check_gpu(exp_avg_sqs[i], "exp_avg_sq");
+        const int64_t ne = params[i].numel();
+        TORCH_CHECK(grads[i].numel() == ne && exp_avgs[i].numel() == ne && exp_avg_sqs[i].numel() == ne,
+                    "adamw_step: element counts differ at index ", i);
+        TORCH_CHECK(exp_avgs[i].scalar_type() == at::kFloat && exp_avg_sqs[i].scalar_type() == at::kFloat,
+                    "adamw_step: moments must be float32");
+        TORCH_CHECK(grads[i].get_device() == params[i].get_device() && exp_avgs[i].get_device() == params[i].get_device() &&
+                        exp_avg_sqs[i].get_device() == params[i].get_device(), "adamw_step: device mismatch at index ", i);
+        if (kdtype(params[i]) != pd || kdtype(grads[i]) != gd || ne == 0) continue;
+        float* master = nullptr;
+        if (masters[i].has_value() && masters[i]->defined()) {
+          check_gpu(*masters[i], "master");
+          TORCH_CHECK(masters[i]->scalar_type() == at::kFloat && masters[i]->numel() == ne, "adamw_step: master must be float32 of the same size");
+          master = masters[i]->data_ptr<float>();
+        }
+        if (tab.n == kernels::AdamWTable::kMaxTensors) flush();
+        const int k = tab.n;
+        tab.param[k] = params[i].data_ptr();
+        tab.grad[k] = grads[i].data_ptr();
+        tab.exp_avg[k] = exp_avgs[i].data_ptr<float>();
+        tab.exp_avg_sq[k] = exp_avg_sqs[i].data_ptr<float>();
+        tab.master[k] = master;
+        tab.numel[k] = ne;
+        tab.block_start[k + 1] = tab.block_start[k] + static_cast<int>((ne + kernels::AdamWTable::kChunk - 1) / kernels::AdamWTable::kChunk);
+        tab.n = k + 1;
+      }
+      flush();
+    }
+}
+
+void grad_sumsq(const std::vector<Tensor>& tensors, Tensor out) {
+  check_gpu(out, "out");
+  TORCH_CHECK(out.scalar_type() == at::kFloat && out.numel() >= 1, "grad_sumsq: float32 accumulator expected");
+  if (tensors.empty()) return;
+  DevGuard g(out);
+  hipStream_t stream = stream_of(out);
+  for (int dt = 0; dt < 3; ++dt) {
+    kernels::CopyTable tab;
+    tab.n = 0;
+    tab.block_start[0] = 0;
+    auto flush = [&]() {
+      if (tab.n > 0) kernels::launch_sumsq(tab, dt, out.data_ptr<float>(), stream);
+      tab.n = 0;
+      tab.block_start[0] = 0;
+    };
+    for (const Tensor& t : tensors) {
+      check_gpu(t, "tensor");
+      TORCH_CHECK(t.get_device() == out.get_device(), "grad_sumsq: device mismatch");
+      if (kdtype(t) != dt || t.numel() == 0) continue;
+      if (tab.n == kernels::CopyTable::kMaxTensors) flush();
+      const int k = tab.n;
+      tab.src[k] = t.data_ptr();
+      tab.dst[k] = nullptr;
+      tab.numel[k] = t.numel();
+      tab.block_start[k + 1] = tab.block_start[k] + static_cast<int>((t.numel() + kernels::CopyTable::kChunk - 1) / kernels::CopyTable::kChunk);
+      tab.n = k + 1;
+    }
+    flush();
+  }
+}
+
+void clip_coef(Tensor sumsq, double max_norm, Tensor coef, Tensor norm_out) {
+  check_gpu(sumsq, "sumsq");
+  check_gpu(coef, "coef");
+  check_gpu(norm_out, "norm_out");
+  TORCH_CHECK(sumsq.scalar_type() == at::kFloat && coef.scalar_type() == at::kFloat && norm_out.scalar_type() == at::kFloat,
+              "clip_coef: float32 scalars expected");
+  DevGuard g(sumsq);
+  kernels::launch_clip_coef(sumsq.data_ptr<float>(), static_cast<float>(max_norm), coef.data_ptr<float>(), norm_out.data_ptr<float>(), stream_of(sumsq));
+}
+
+// ------------------------------------------------------------------ softmax cross-entropy
+// logits: [N, ld]; only the first n_classes columns are real (n_classes <= 0 means all).
+std::tuple<Tensor, Tensor, Tensor, Tensor> xent_forward(Tensor logits, Tensor targets, int64_t n_classes, int64_t ignore_index) {
+  check_gpu(logits, "logits");
+  check_gpu(targets, "targets");
+  TORCH_CHECK(logits.dim() == 2, "logits must be [N, C]");
+  TORCH_CHECK(targets.dim() == 1 && targets.size(0) == logits.size(0), "targets must be [N]");
+  TORCH_CHECK(targets.scalar_type() == at::kLong, "targets must be int64");
+  TORCH_CHECK(targets.get_device() == logits.get_device(), "logits and targets on different devices");
+  const int64_t N = logits.size(0), ld = logits.size(1);
+  const int64_t C = n_classes > 0 ? n_classes : ld;
+  TORCH_CHECK(C <= ld, "n_classes exceeds the logits width");
+  TORCH_CHECK(N < (1ll << 31), "too many rows");
+  auto fopt = logits.options().dtype(at::kFloat);
+  Tensor row_loss = at::empty({N}, fopt), row_lse = at::empty({N}, fopt);
+  Tensor correct = at::empty({N}, logits.options().dtype(at::kBool));
+  Tensor metrics = at::empty({4}, fopt);
+  DevGuard g(logits);
+  hipStream_t s = stream_of(logits);
+  kernels::launch_xent_fwd(logits.data_ptr(), kdtype(logits), reinterpret_cast<const long long*>(targets.data_ptr<int64_t>()), N, C, ld,
+                           ignore_index, row_loss.data_ptr<float>(), row_lse.data_ptr<float>(),
+                           reinterpret_cast<unsigned char*>(correct.data_ptr<bool>()), s);
+  kernels::launch_xent_reduce(row_loss.data_ptr<float>(), reinterpret_cast<const unsigned char*>(correct.data_ptr<bool>()),
+                              reinterpret_cast<const long long*>(targets.data_ptr<int64_t>()), N, ignore_index,
+                              metrics.data_ptr<float>(), s);
+  return {row_loss, row_lse, correct, metrics};
+}
+
+Tensor xent_backward(Tensor logits, Tensor targets, Tensor row_lse, Tensor grad_out, Tensor metrics, bool mean,
+                     int64_t n_classes, int64_t ignore_index, bool inplace) {
+  check_gpu(logits, "logits");
+  check_gpu(targets, "targets");
+  check_gpu(row_lse, "row_lse");
+  check_gpu(grad_out, "grad_out");
+  check_gpu(metrics, "metrics");
+  TORCH_CHECK(logits.dim() == 2 && targets.numel() == logits.size(0) && row_lse.numel() == logits.size(0), "xent_backward: shape mismatch");
+  TORCH_CHECK(targets.scalar_type() == at::kLong && row_lse.scalar_type() == at::kFloat && metrics.scalar_type() == at::kFloat &&
+                  metrics.numel() >= 4, "xent_backward: dtype mismatch");
+  TORCH_CHECK(grad_out.scalar_type() == at::kFloat && grad_out.numel() == 1, "xent_backward: grad_out must be a float32 scalar");
+  const int64_t N = logits.size(0), ld = logits.size(1);
+  const int64_t C = n_classes > 0 ? n_classes : ld;
+  TORCH_CHECK(C <= ld, "n_classes exceeds the logits width");
+  Tensor dlogits = inplace ? logits : at::empty_like(logits);
+  DevGuard g(logits);
+  kernels::launch_xent_bwd(logits.data_ptr(), kdtype(logits), reinterpret_cast<const long long*>(targets.data_ptr<int64_t>()),
+                           row_lse.data_ptr<float>(), grad_out.data_ptr<float>(), metrics.data_ptr<float>(), mean ? 1 : 0, N, C, ld,
+                           ignore_index, dlogits.data_ptr(), stream_of(logits));
+  return dlogits;
+}
+
+// ------------------------------------------------------------------ linear layers
+bool gemm_path_ok(const kernels::GemmArgs& a, int dt) {
+  return dt == kernels::kF32 ? kernels::gemm_f32_supported(a) : (dt == kernels::kBF16 ? kernels::gemm_bf16_supported(a) : false);
+}
+
+void run_gemm(const kernels::GemmArgs& a, int dt, hipStream_t s) {
+  if (dt == kernels::kF32) kernels::launch_gemm_f32(a, s);
+  else kernels::launch_gemm_bf16(a, s);
+}
+
+// Which kernel family a y = x W^T (+b) product of this shape runs on.
+std::string linear_route(int64_t M, int64_t N, int64_t K, int dt) {
+  if (K == 1) return "outer";
+  if (N <= 16) return "skinny";
+  kernels::GemmArgs a{};
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N; a.a_kmajor = 1; a.b_kmajor = 1;
+  return gemm_path_ok(a, dt) ? "mfma" : "unsupported";
+}
+
+// y = act(x W^T + b).  x: [M, K], W: [N, K], b: [N] or None.  Returns (y, pre_activation or None).
+std::tuple<Tensor, c10::optional<Tensor>> linear_forward(Tensor x, Tensor w, c10::optional<Tensor> bias, int64_t act, bool save_pre_act) {
+  check_gpu(x, "x");
+  check_gpu(w, "weight");
+  TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && x.size(1) == w.size(1), "linear_forward: x [M,K] and weight [N,K] expected");
+  TORCH_CHECK(x.scalar_type() == w.scalar_type(), "linear_forward: x and weight dtypes differ");
+  TORCH_CHECK(x.get_device() == w.get_device(), "linear_forward: device mismatch");
+  const void* bptr = nullptr;
+  if (bias.has_value() && bias->defined()) {
+    check_gpu(*bias, "bias");
+    TORCH_CHECK(bias->numel() == w.size(0) && bias->scalar_type() == w.scalar_type(), "linear_forward: bias must be [N] in the weight dtype");
+    bptr = bias->data_ptr();
+  }
+  const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
+  const int dt = kdtype(x);
+  Tensor y = at::empty({M, N}, x.options());
+  c10::optional<Tensor> pre;
+  DevGuard g(x);
+  hipStream_t s = stream_of(x);
+  if (M == 0 || N == 0) return {y, pre};
+  if (K == 1) {
+    TORCH_CHECK(!save_pre_act, "linear_forward: pre-activation output is not provided for K == 1");
+    kernels::launch_outer_bias_act(x.data_ptr(), w.data_ptr(), bptr, y.data_ptr(), M, N, dt, static_cast<int>(act), s);
+  } else if (N <= 16) {
+    TORCH_CHECK(act == kernels::kActNone, "linear_forward: no fused activation on the N <= 16 path");
+    kernels::launch_skinny_n(x.data_ptr(), w.data_ptr(), bptr, y.data_ptr(), M, N, K, dt, s);
+  } else {
+    kernels::GemmArgs a{};
+    a.A = x.data_ptr(); a.B = w.data_ptr(); a.C = y.data_ptr(); a.bias = bptr;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
+    a.a_kmajor = 1; a.b_kmajor = 1; a.act = static_cast<int>(act); a.alpha = 1.f; a.beta = 0.f;
+    if (save_pre_act && act != kernels::kActNone) {
+      pre = at::empty({M, N}, x.options());
+      a.pre_act = pre->data_ptr();
+    }
+    TORCH_CHECK(gemm_path_ok(a, dt), "linear_forward: shape M=", M, " N=", N, " K=", K, " is not supported by the MFMA GEMM for dtype ", x.scalar_type());
+    run_gemm(a, dt, s);
+  }
+  return {y, pre};
+}
+
+// Gradients of y = x W^T + b given g = dL/d(xW^T+b).  Returns (dx or None, dW, db or None).
+std::tuple<c10::optional<Tensor>, Tensor, c10::optional<Tensor>> linear_backward(Tensor g, Tensor x, Tensor w, bool need_dx, bool need_db) {
+  check_gpu(g, "grad");
+  check_gpu(x, "x");
+  check_gpu(w, "weight");
+  TORCH_CHECK(g.dim() == 2 && x.dim() == 2 && w.dim() == 2, "linear_backward: 2-D tensors expected");
+  const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
+  TORCH_CHECK(g.size(0) == M && g.size(1) == N && w.size(1) == K, "linear_backward: shape mismatch");
+  TORCH_CHECK(g.scalar_type() == x.scalar_type() && x.scalar_type() == w.scalar_type(), "linear_backward: dtype mismatch");
+  TORCH_CHECK(g.get_device() == x.get_device() && x.get_device() == w.get_device(), "linear_backward: device mismatch");
+  const int dt = kdtype(x);
+  DevGuard guard(x);
+  hipStream_t s = stream_of(x);
+  Tensor dW = at::empty_like(w);
+  c10::optional<Tensor> dx, db;
+  if (need_db) db = at::empty({N}, w.options());
+  if (need_dx) dx = at::empty_like(x);
+  auto fopt = x.options().dtype(at::kFloat);
+  if (K == 1) {
+    Tensor ws = at::empty({kernels::colreduce_workspace(M, N)}, fopt);
+    Tensor db_tmp = need_db ? *db : at::empty({N}, w.options());
+    kernels::launch_outer_wgrad(g.data_ptr(), x.data_ptr(), dW.data_ptr(), db_tmp.data_ptr(), ws.data_ptr<float>(), M, N, dt, s);
+    if (need_dx) {
+      // dx[m] = sum_n g[m,n] w[n]: a skinny product with a single output column.
+      kernels::launch_skinny_n(g.data_ptr(), w.data_ptr(), nullptr, dx->data_ptr(), M, 1, N, dt, s);
+    }
+  } else if (N <= 16) {
+    Tensor ws = at::empty({kernels::skinny_wgrad_workspace(M, N, K)}, fopt);
+    kernels::launch_skinny_n_wgrad(g.data_ptr(), x.data_ptr(), dW.data_ptr(), need_db ? db->data_ptr() : nullptr, ws.data_ptr<float>(), M, N, K, dt, s);
+    if (need_dx) kernels::launch_skinny_n_dgrad(g.data_ptr(), w.data_ptr(), dx->data_ptr(), M, N, K, dt, s);
+  } else {
+    // dW[N,K] = g^T x : contraction over M; both operands are stored with the contraction dim slowest.
+    kernels::GemmArgs a{};
+    a.A = g.data_ptr(); a.B = x.data_ptr(); a.C = dW.data_ptr();
+    a.M = N; a.N = K; a.K = M; a.lda = N; a.ldb = K; a.ldc = K; a.a_kmajor = 0; a.b_kmajor = 0; a.alpha = 1.f;
+    TORCH_CHECK(gemm_path_ok(a, dt), "linear_backward: weight-gradient shape not supported by the MFMA GEMM");
+    run_gemm(a, dt, s);
+    if (need_dx) {
+      // dx[M,K] = g W : contraction over N; A = g is contraction-contiguous, B = W is stored [N(contraction), K].
+      kernels::GemmArgs b{};
+      b.A = g.data_ptr(); b.B = w.data_ptr(); b.C = dx->data_ptr();
+      b.M = M; b.N = K; b.K = N; b.lda = N; b.ldb = K; b.ldc = K; b.a_kmajor = 1; b.b_kmajor = 0; b.alpha = 1.f;
+      TORCH_CHECK(gemm_path_ok(b, dt), "linear_backward: input-gradient shape not supported by the MFMA GEMM");
+      run_gemm(b, dt, s);
+    }
+    if (need_db) {
+      Tensor ws = at::empty({kernels::colreduce_workspace(M, N)}, fopt);
+      kernels::launch_colsum(g.data_ptr(), db->data_ptr(), ws.data_ptr<float>(), M, N, dt, s);
+    }
+  }
+  return {dx, dW, db};
+}
+
+// g = dy * act'(saved) and optionally db = colsum(g).  saved: output y for ReLU, pre-activation for GELU.
+std::tuple<Tensor, c10::optional<Tensor>> act_backward(Tensor dy, Tensor saved, int64_t act, bool need_db) {
+  check_gpu(dy, "dy");
+  check_gpu(saved, "saved");
+  TORCH_CHECK(dy.dim() == 2 && saved.sizes() == dy.sizes() && saved.scalar_type() == dy.scalar_type(), "act_backward: shape/dtype mismatch");
+  TORCH_CHECK(dy.get_device() == saved.get_device(), "act_backward: device mismatch");
+  const int64_t M = dy.size(0), N = dy.size(1);
+  Tensor gout = at::empty_like(dy);
+  c10::optional<Tensor> db;
+  if (need_db) db = at::empty({N}, dy.options());
+  Tensor ws = at::empty({kernels::colreduce_workspace(M, N)}, dy.options().dtype(at::kFloat));
+  DevGuard guard(dy);
+  kernels::launch_act_bwd(dy.data_ptr(), saved.data_ptr(), gout.data_ptr(), need_db ? db->data_ptr() : nullptr, ws.data_ptr<float>(), M, N,
+                          kdtype(dy), static_cast<int>(act), stream_of(dy));
+  return {gout, db};
+}
+
+// General matrix product on the MFMA kernels (used by tests and benchmarks):
+// C[M,N] = alpha * op(A) op(B)^T with the layout flags of kernels::GemmArgs.
+Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tensor> bias, int64_t act) {
+  check_gpu(A, "A");
+  check_gpu(B, "B");
+  TORCH_CHECK(A.dim() == 2 && B.dim() == 2 && A.scalar_type() == B.scalar_type(), "gemm: 2-D tensors of one dtype expected");
+  TORCH_CHECK(A.get_device() == B.get_device(), "gemm: device mismatch");
+  const int64_t M = a_kmajor ? A.size(0) : A.size(1);
+  const int64_t K = a_kmajor ? A.size(1) : A.size(0);
+  const int64_t N = b_kmajor ? B.size(0) : B.size(1);
+  const int64_t Kb = b_kmajor ? B.size(1) : B.size(0);
+  TORCH_CHECK(K == Kb, "gemm: contraction sizes differ (", K, " vs ", Kb, ")");
+  Tensor C = at::empty({M, N}, A.options());
+  kernels::GemmArgs a{};
+  a.A = A.data_ptr(); a.B = B.data_ptr(); a.C = C.data_ptr();
+  if (bias.has_value() && bias->defined()) {
+    check_gpu(*bias, "bias");
+    TORCH_CHECK(bias->numel() == N && bias->scalar_type() == A.scalar_type(), "gemm: bias must be [N] in the operand dtype");
+    a.bias = bias->data_ptr();
+  }
+  a.M = M; a.N = N; a.K = K; a.lda = A.size(1); a.ldb = B.size(1); a.ldc = N;
+  a.a_kmajor = a_kmajor; a.b_kmajor = b_kmajor; a.act = static_cast<int>(act); a.alpha = 1.f; a.beta = 0.f;
+  const int dt = kdtype(A);
+  TORCH_CHECK(gemm_path_ok(a, dt), "gemm: shape M=", M, " N=", N, " K=", K, " not supported for dtype ", A.scalar_type());
+  DevGuard guard(A);
+  run_gemm(a, dt, stream_of(A));
+  return C;
+}
+
+// ------------------------------------------------------------------ layer norm
+std::tuple<Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor gamma, Tensor beta, double eps) {
+  check_gpu(x, "x");
+  check_gpu(gamma, "weight");
+  check_gpu(beta, "bias");
+  TORCH_CHECK(x.dim() == 2, "layernorm_forward: x must be [rows, cols]");
+  const int64_t rows = x.size(0), cols = x.size(1);
+  TORCH_CHECK(gamma.numel() == cols && beta.numel() == cols, "layernorm_forward: affine parameters must be [cols]");
+  TORCH_CHECK(gamma.scalar_type() == x.scalar_type() && beta.scalar_type() == x.scalar_type(), "layernorm_forward: dtype mismatch");
+  {
+    const int64_t vec = 16 / x.element_size();
+    TORCH_CHECK(cols % vec == 0 && cols <= 64 * vec * 8, "layernorm_forward: cols must be a multiple of ", vec, " and at most ", 64 * vec * 8);
+  }
+  Tensor y = at::empty_like(x);
+  auto fopt = x.options().dtype(at::kFloat);
+  Tensor mean = at::empty({rows}, fopt), rstd = at::empty({rows}, fopt);
+  DevGuard guard(x);
+  kernels::launch_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
+                                rows, cols, static_cast<float>(eps), kdtype(x), stream_of(x));
+  return {y, mean, rstd};
+}
+
+std::tuple<Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tensor gamma, Tensor mean, Tensor rstd) {
+  check_gpu(dy, "dy");
+  check_gpu(x, "x");
+  check_gpu(gamma, "weight");
+  check_gpu(mean, "mean");
+  check_gpu(rstd, "rstd");
+  TORCH_CHECK(x.dim() == 2 && dy.sizes() == x.sizes() && dy.scalar_type() == x.scalar_type(), "layernorm_backward: shape/dtype mismatch");
+  const int64_t rows = x.size(0), cols = x.size(1);
+  TORCH_CHECK(gamma.numel() == cols && mean.numel() == rows && rstd.numel() == rows, "layernorm_backward: size mismatch");
+  TORCH_CHECK(mean.scalar_type() == at::kFloat && rstd.scalar_type() == at::kFloat, "layernorm_backward: statistics must be float32");
+  {
+    const int64_t vec = 16 / x.element_size();
+    TORCH_CHECK(cols % vec == 0 && cols <= 64 * vec * 4, "layernorm_backward: cols must be a multiple of ", vec, " and at most ", 64 * vec * 4);
+  }
+  Tensor dx = at::empty_like(x), dgamma = at::empty_like(gamma), dbeta = at::empty_like(gamma);
+  Tensor ws = at::empty({kernels::layernorm_bwd_workspace(rows, cols)}, x.options().dtype(at::kFloat));
+  DevGuard guard(x);
+  kernels::launch_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(), dx.data_ptr(),
+                                dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr<float>(), rows, cols, kdtype(x), stream_of(x));
+  return {dx, dgamma, dbeta};
+}
+
+}  // namespace
+
+void init_ops(py::module_& m) {
+  m.def("multi_copy_scale", &multi_copy_scale, py::arg("srcs"), py::arg("dsts"), py::arg("scale") = 1.0);
+  m.def("scale_inplace", &scale_inplace);
+  m.def("adamw_tick", &adamw_tick);
+  m.def("adamw_step", &adamw_step, py::arg("params"), py::arg("grads"), py::arg("exp_avgs"), py::arg("exp_avg_sqs"), py::arg("masters"),
+        py::arg("hparams"), py::arg("grad_scale") = py::none());
+  m.def("grad_sumsq", &grad_sumsq);
+  m.def("clip_coef", &clip_coef);
+  m.def("xent_forward", &xent_forward, py::arg("logits"), py::arg("targets"), py::arg("n_classes") = -1, py::arg("ignore_index") = -100);
+  m.def("xent_backward", &xent_backward, py::arg("logits"), py::arg("targets"), py::arg("row_lse"), py::arg("grad_out"), py::arg("metrics"),
+        py::arg("mean") = true, py::arg("n_classes") = -1, py::arg("ignore_index") = -100, py::arg("inplace") = false);
+  m.def("linear_route", [](int64_t M, int64_t N, int64_t K, const std::string& dtype) {
+    const int dt = dtype == "float32" ? kernels::kF32 : (dtype == "bfloat16" ? kernels::kBF16 : kernels::kF16);
+    return linear_route(M, N, K, dt);
+  });
+  m.def("linear_forward", &linear_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("act") = 0, py::arg("save_pre_act") = false);
+  m.def("linear_backward", &linear_backward, py::arg("grad"), py::arg("x"), py::arg("weight"), py::arg("need_dx") = true, py::arg("need_db") = true);
+  m.def("act_backward", &act_backward, py::arg("dy"), py::arg("saved"), py::arg("act"), py::arg("need_db") = false);
+  m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),
+        py::arg("act") = 0);
+  m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5);
+  m.def("layernorm_backward", &layernorm_backward);
+  m.attr("ACT_NONE") = static_cast<int>(kernels::kActNone);
+  m.attr("ACT_RELU") = static_cast<int>(kernels::kActRelu);
+  m.attr("ACT_GELU") = static_cast<int>(kernels::kActGelu);
+}

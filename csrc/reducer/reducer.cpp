@@ -1,0 +1,348 @@
+#include "reducer.h"
+
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/engine.h>
+#include <torch/csrc/autograd/utils/lambda_post_hook.h>
+#include <torch/csrc/autograd/variable.h>
+
+#include <stdexcept>
+
+#include "kernels/kernels.h"
+
+namespace dpa {
+
+namespace {
+
+int kernel_dtype(at::ScalarType t) {
+  switch (t) {
+    case at::kFloat: return kernels::kF32;
+    case at::kBFloat16: return kernels::kBF16;
+    case at::kHalf: return kernels::kF16;
+    default: return -1;
+  }
+}
+
+hipStream_t current_stream_of(const at::Tensor& t) {
+  return c10::hip::getCurrentHIPStream(static_cast<c10::DeviceIndex>(t.get_device())).stream();
+}
+
+// Appends (src -> dst) to a copy table, flushing it through `flush` when it is full.
+template <typename Flush>
+void table_add(kernels::CopyTable& tab, const void* src, void* dst, int64_t numel, Flush&& flush) {
+  if (numel <= 0) return;
+  if (tab.n == kernels::CopyTable::kMaxTensors) {
+    flush(tab);
+    tab.n = 0;
+    tab.block_start[0] = 0;
+  }
+  const int i = tab.n;
+  tab.src[i] = src;
+  tab.dst[i] = dst;
+  tab.numel[i] = numel;
+  const int blocks = static_cast<int>((numel + kernels::CopyTable::kChunk - 1) / kernels::CopyTable::kChunk);
+  tab.block_start[i + 1] = tab.block_start[i] + blocks;
+  tab.n = i + 1;
+}
+
+// ------------------------------------------------------------------ transports
+class RcclTransport final : public Transport {
+ public:
+  explicit RcclTransport(std::shared_ptr<RcclComm> c) : comm_(std::move(c)) {}
+  bool native_average() const override { return true; }
+  void all_reduce_async(at::Tensor flat, int slot, bool average) override {
+    comm_->all_reduce_async(flat, average ? static_cast<int>(ncclAvg) : static_cast<int>(ncclSum), slot);
+  }
+  void broadcast(at::Tensor flat, int root) override { comm_->broadcast(flat, root); }
+  void wait_all() override { comm_->wait_all_slots(); }
+  int world() const override { return comm_->world(); }
+
+ private:
+  std::shared_ptr<RcclComm> comm_;
+};
+
+class C10dTransport final : public Transport {
+ public:
+  explicit C10dTransport(c10::intrusive_ptr<c10d::ProcessGroup> pg) : pg_(std::move(pg)) {}
+  bool native_average() const override { return false; }
+  void all_reduce_async(at::Tensor flat, int /*slot*/, bool /*average: pre-divided by the reducer*/) override {
+    std::vector<at::Tensor> ts{flat};
+    c10d::AllreduceOptions o;
+    o.reduceOp = c10d::ReduceOp::SUM;
+    works_.push_back(pg_->allreduce(ts, o));
+  }
+  void broadcast(at::Tensor flat, int root) override {
+    std::vector<at::Tensor> ts{flat};
+    c10d::BroadcastOptions o;
+    o.rootRank = root;
+    pg_->broadcast(ts, o)->wait();
+  }
+  void wait_all() override {
+    for (auto& w : works_) w->wait();
+    works_.clear();
+  }
+  int world() const override { return pg_->getSize(); }
+
+ private:
+  c10::intrusive_ptr<c10d::ProcessGroup> pg_;
+  std::vector<c10::intrusive_ptr<c10d::Work>> works_;
+};
+
+class LocalTransport final : public Transport {
+ public:
+  bool native_average() const override { return true; }
+  void all_reduce_async(at::Tensor, int, bool) override {}
+  void broadcast(at::Tensor, int) override {}
+  void wait_all() override {}
+  int world() const override { return 1; }
+};
+
+}  // namespace
+
+std::shared_ptr<Transport> make_rccl_transport(std::shared_ptr<RcclComm> comm) {
+  return std::make_shared<RcclTransport>(std::move(comm));
+}
+std::shared_ptr<Transport> make_c10d_transport(c10::intrusive_ptr<c10d::ProcessGroup> pg) {
+  return std::make_shared<C10dTransport>(std::move(pg));
+}
+std::shared_ptr<Transport> make_local_transport() { return std::make_shared<LocalTransport>(); }
+
+// ------------------------------------------------------------------ reducer
+Reducer::Reducer(std::vector<at::Tensor> params, std::vector<BucketSpec> buckets, std::shared_ptr<Transport> transport,
+                 ReducerOptions options)
+    : params_(std::move(params)), transport_(std::move(transport)), opt_(options) {
+  locator_.assign(params_.size(), {-1, -1});
+  buckets_.reserve(buckets.size());
+  for (size_t b = 0; b < buckets.size(); ++b) {
+    BucketState bs;
+    bs.spec = std::move(buckets[b]);
+    const auto& sp = bs.spec;
+    if (sp.param_indices.size() != sp.offsets.size()) throw std::invalid_argument("Reducer: indices/offsets size mismatch");
+    if (!sp.buffer.defined() || sp.buffer.dim() != 1 || !sp.buffer.is_contiguous())
+      throw std::invalid_argument("Reducer: bucket buffer must be a contiguous 1-D tensor");
+    for (size_t j = 0; j < sp.param_indices.size(); ++j) {
+      const int64_t pi = sp.param_indices[j];
+      if (pi < 0 || pi >= static_cast<int64_t>(params_.size())) throw std::out_of_range("Reducer: parameter index out of range");
+      if (locator_[static_cast<size_t>(pi)].first >= 0) throw std::invalid_argument("Reducer: parameter assigned to two buckets");
+      const at::Tensor& p = params_[static_cast<size_t>(pi)];
+      if (p.device() != sp.buffer.device()) throw std::invalid_argument("Reducer: parameter and bucket on different devices");
+      if (sp.offsets[j] < 0 || sp.offsets[j] + p.numel() > sp.buffer.numel())
+        throw std::out_of_range("Reducer: tensor does not fit its bucket slice");
+      locator_[static_cast<size_t>(pi)] = {static_cast<int64_t>(b), static_cast<int64_t>(j)};
+      bs.views.push_back(sp.buffer.narrow(0, sp.offsets[j], p.numel()).view(p.sizes()));
+    }
+    bs.ready.assign(sp.param_indices.size(), 0);
+    bs.pending = static_cast<int64_t>(sp.param_indices.size());
+    buckets_.push_back(std::move(bs));
+  }
+  for (size_t i = 0; i < params_.size(); ++i) {
+    if (!params_[i].requires_grad()) continue;
+    if (locator_[i].first < 0) throw std::invalid_argument("Reducer: a parameter that requires grad is in no bucket");
+    auto acc = torch::autograd::impl::grad_accumulator(params_[i]);
+    const int64_t idx = static_cast<int64_t>(i);
+    uintptr_t key = acc->add_post_hook(std::make_unique<torch::autograd::utils::LambdaPostHook>(
+        [this, idx](const torch::autograd::variable_list& outputs, const torch::autograd::variable_list& /*inputs*/) {
+          this->autograd_hook(idx);
+          return outputs;
+        }));
+    hooks_.emplace_back(key, std::move(acc));
+  }
+}
+
+Reducer::~Reducer() { detach(); }
+
+void Reducer::detach() {
+  for (auto& h : hooks_) h.second->del_post_hook(h.first);
+  hooks_.clear();
+}
+
+void Reducer::prepare_for_backward(bool sync) {
+  std::lock_guard<std::mutex> g(mu_);
+  armed_ = sync;
+  callback_queued_ = false;
+  next_bucket_ = 0;
+  ready_order_.clear();
+  for (auto& bs : buckets_) {
+    bs.pending = static_cast<int64_t>(bs.spec.param_indices.size());
+    bs.launched = false;
+    std::fill(bs.ready.begin(), bs.ready.end(), 0);
+  }
+}
+
+void Reducer::autograd_hook(int64_t param_index) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!armed_) return;
+  if (!callback_queued_) {
+    callback_queued_ = true;
+    torch::autograd::Engine::get_default_engine().queue_callback([this] { this->finalize_backward(); });
+  }
+  const auto loc = locator_[static_cast<size_t>(param_index)];
+  BucketState& bs = buckets_[static_cast<size_t>(loc.first)];
+  if (bs.launched)
+    throw std::runtime_error(
+        "Reducer: a parameter produced a second gradient after its bucket was already reduced in this backward pass "
+        "(parameter used in several backward graphs: wrap the extra passes in no_sync())");
+  if (bs.ready[static_cast<size_t>(loc.second)]) return;  // same parameter hit twice before launch: grad already accumulated
+  bs.ready[static_cast<size_t>(loc.second)] = 1;
+  ready_order_.push_back(param_index);
+  if (--bs.pending == 0) launch_ready_buckets();
+}
+
+void Reducer::launch_ready_buckets() {
+  while (next_bucket_ < buckets_.size() && buckets_[next_bucket_].pending == 0) {
+    launch_bucket(next_bucket_);
+    ++next_bucket_;
+  }
+}
+
+void Reducer::pack_into_bucket(BucketState& bs, const std::vector<int64_t>& local_ids, float scale) {
+  if (local_ids.empty()) return;
+  const at::Tensor& buf = bs.spec.buffer;
+  const int dst_dt = kernel_dtype(buf.scalar_type());
+  bool gpu_fast = buf.is_cuda() && dst_dt >= 0;
+  if (gpu_fast) {
+    for (int64_t j : local_ids) {
+      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
+      if (!g.is_contiguous() || kernel_dtype(g.scalar_type()) < 0 || !g.is_cuda()) gpu_fast = false;
+    }
+  }
+  if (!gpu_fast) {
+    for (int64_t j : local_ids) {
+      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
+      at::Tensor& v = bs.views[static_cast<size_t>(j)];
+      v.copy_(g);
+      if (scale != 1.f) v.mul_(scale);
+    }
+    return;
+  }
+  hipStream_t stream = current_stream_of(buf);
+  // Source dtypes may differ per tensor in principle; group launches by source dtype.
+  for (int src_dt = 0; src_dt < 3; ++src_dt) {
+    kernels::CopyTable tab;
+    tab.n = 0;
+    tab.block_start[0] = 0;
+    auto flush = [&](kernels::CopyTable& t) {
+      kernels::launch_multi_copy_scale(t, src_dt, dst_dt, scale, stream);
+      ++n_pack_launches_;
+    };
+    for (int64_t j : local_ids) {
+      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
+      if (kernel_dtype(g.scalar_type()) != src_dt) continue;
+      table_add(tab, g.data_ptr(), bs.views[static_cast<size_t>(j)].data_ptr(), g.numel(), flush);
+    }
+    if (tab.n > 0) flush(tab);
+  }
+}
+
+void Reducer::unpack_from_bucket(BucketState& bs) {
+  const at::Tensor& buf = bs.spec.buffer;
+  const int src_dt = kernel_dtype(buf.scalar_type());
+  std::vector<int64_t> todo;
+  for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
+    at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
+    const at::Tensor& g = p.grad();
+    if (!g.defined()) {
+      // Locally unused parameter: it still receives the globally reduced gradient.
+      p.mutable_grad() = bs.views[j].to(p.scalar_type());
+      continue;
+    }
+    if (g.data_ptr() == bs.views[j].data_ptr()) continue;
+    todo.push_back(static_cast<int64_t>(j));
+  }
+  if (todo.empty()) return;
+  bool gpu_fast = buf.is_cuda() && src_dt >= 0;
+  if (gpu_fast)
+    for (int64_t j : todo) {
+      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
+      if (!g.is_contiguous() || kernel_dtype(g.scalar_type()) < 0) gpu_fast = false;
+    }
+  if (!gpu_fast) {
+    for (int64_t j : todo)
+      params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].mutable_grad().copy_(bs.views[static_cast<size_t>(j)]);
+    return;
+  }
+  hipStream_t stream = current_stream_of(buf);
+  for (int dst_dt = 0; dst_dt < 3; ++dst_dt) {
+    kernels::CopyTable tab;
+    tab.n = 0;
+    tab.block_start[0] = 0;
+    auto flush = [&](kernels::CopyTable& t) {
+      kernels::launch_multi_copy_scale(t, src_dt, dst_dt, 1.f, stream);
+      ++n_pack_launches_;
+    };
+    for (int64_t j : todo) {
+      at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].mutable_grad();
+      if (kernel_dtype(g.scalar_type()) != dst_dt) continue;
+      table_add(tab, bs.views[static_cast<size_t>(j)].data_ptr(), g.data_ptr(), g.numel(), flush);
+    }
+    if (tab.n > 0) flush(tab);
+  }
+}
+
+void Reducer::launch_bucket(size_t b) {
+  BucketState& bs = buckets_[b];
+  const bool pre_divide = !transport_->native_average() && transport_->world() > 1;
+  const float scale = pre_divide ? 1.f / static_cast<float>(transport_->world()) : 1.f;
+  std::vector<int64_t> to_copy;
+  bool any_view = false;
+  for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
+    at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
+    const at::Tensor& g = p.grad();
+    at::Tensor& v = bs.views[j];
+    if (!bs.ready[j] || !g.defined()) {
+      v.zero_();  // no gradient produced locally: contributes zeros
+    } else if (g.data_ptr() == v.data_ptr()) {
+      any_view = true;  // accumulated in place inside the bucket
+      if (pre_divide) v.mul_(scale);
+    } else {
+      to_copy.push_back(static_cast<int64_t>(j));
+    }
+  }
+  (void)any_view;
+  pack_into_bucket(bs, to_copy, scale);
+  if (opt_.gradient_as_bucket_view) {
+    for (int64_t j : to_copy) {
+      at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])];
+      if (p.scalar_type() == bs.spec.buffer.scalar_type()) p.mutable_grad() = bs.views[static_cast<size_t>(j)];
+    }
+  }
+  transport_->all_reduce_async(bs.spec.buffer, static_cast<int>(b), /*average=*/true);
+  bs.launched = true;
+  ++n_launches_;
+}
+
+void Reducer::finalize_backward() {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!armed_) return;
+  // Buckets that never filled up (parameters without a gradient this iteration) go out now,
+  // still in index order, so the collective sequence is identical on every rank.
+  for (size_t b = next_bucket_; b < buckets_.size(); ++b) launch_bucket(b);
+  next_bucket_ = buckets_.size();
+  transport_->wait_all();
+  if (opt_.unpack_to_grads)
+    for (auto& bs : buckets_) unpack_from_bucket(bs);
+  armed_ = false;
+  callback_queued_ = false;
+  last_ready_order_ = ready_order_;
+  ++n_syncs_;
+}
+
+void Reducer::broadcast_parameters(int root) {
+  // Parameters are sent bucket by bucket through the (already allocated) gradient buffers:
+  // pack -> broadcast -> unpack, so no second flat copy of the model is needed.
+  for (auto& bs : buckets_) {
+    for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
+      const at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
+      at::NoGradGuard ng;
+      bs.views[j].copy_(p.detach());
+    }
+    transport_->broadcast(bs.spec.buffer, root);
+    for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
+      at::Tensor p = params_[static_cast<size_t>(bs.spec.param_indices[j])].detach();
+      at::NoGradGuard ng;
+      p.copy_(bs.views[j]);
+    }
+    bs.spec.buffer.zero_();
+  }
+}
+
+}  // namespace dpa

@@ -1,0 +1,114 @@
+// Gradient reducer: bucketed, overlapped all-reduce driven from autograd hooks.
+//
+// Owns what torch's C++ Reducer does for the DistributedDataParallel wrapper the reference
+// builds in prepare_ddp_model (reference distributed.py:112-115), re-designed around flat
+// arenas:
+//   * every bucket is a slice of one flat buffer laid out by the planner (bucket_plan.h);
+//   * a grad-accumulator post hook per parameter counts the bucket down; a complete bucket
+//     is packed by ONE multi-tensor HIP launch (flatten + pre-divide + dtype cast) and its
+//     all-reduce is queued on the communication stream while backward keeps running;
+//   * buckets are always launched in index order, so every rank issues the same sequence
+//     of collectives even when gradients become ready in a different order;
+//   * with gradient-as-bucket-view the parameter's .grad is re-pointed at its slice, so no
+//     unflatten copy exists and a fused optimizer can sweep the arena in one launch;
+//   * an end-of-backward callback launches buckets that never completed (parameters that
+//     received no gradient contribute zeros) and makes the compute stream wait for the
+//     communication stream before the optimizer may run.
+// The data plane is abstract (`Transport`): RCCL on the GPU, a c10d group (gloo) on the CPU.
+#pragma once
+
+#include <ATen/ATen.h>
+#include <torch/csrc/autograd/function.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "comm/rccl_comm.h"
+
+namespace dpa {
+
+class Transport {
+ public:
+  virtual ~Transport() = default;
+  // True when the transport averages by itself (ncclAvg); otherwise the reducer pre-divides.
+  virtual bool native_average() const = 0;
+  virtual void all_reduce_async(at::Tensor flat, int slot, bool average) = 0;
+  virtual void broadcast(at::Tensor flat, int root) = 0;
+  // Make the consumer of the buckets (current stream / host thread) wait for all pending ops.
+  virtual void wait_all() = 0;
+  virtual int world() const = 0;
+};
+
+std::shared_ptr<Transport> make_rccl_transport(std::shared_ptr<RcclComm> comm);
+std::shared_ptr<Transport> make_c10d_transport(c10::intrusive_ptr<c10d::ProcessGroup> pg);
+// Single-process transport (world 1): no communication, used by tests and to exercise the
+// bucket life cycle on one GPU.
+std::shared_ptr<Transport> make_local_transport();
+
+struct BucketSpec {
+  std::vector<int64_t> param_indices;
+  std::vector<int64_t> offsets;  // element offsets inside the bucket buffer
+  at::Tensor buffer;             // flat [numel] tensor in the reduce dtype
+};
+
+struct ReducerOptions {
+  bool gradient_as_bucket_view = true;
+  bool unpack_to_grads = true;  // when .grad is not a view: copy reduced values back into .grad
+};
+
+class Reducer {
+ public:
+  Reducer(std::vector<at::Tensor> params, std::vector<BucketSpec> buckets,
+          std::shared_ptr<Transport> transport, ReducerOptions options);
+  ~Reducer();
+
+  // Arms the hooks for the backward pass that follows.  sync=false: gradients only
+  // accumulate locally (no_sync()).
+  void prepare_for_backward(bool sync);
+  bool armed() const { return armed_; }
+  // Parameter indices in the order their gradients became ready in the last synced backward.
+  std::vector<int64_t> ready_order() const { return last_ready_order_; }
+  int64_t num_buckets() const { return static_cast<int64_t>(buckets_.size()); }
+  // Counters for tests / tracing.
+  int64_t num_backward_syncs() const { return n_syncs_; }
+  int64_t num_bucket_launches() const { return n_launches_; }
+  int64_t num_pack_launches() const { return n_pack_launches_; }
+  // Broadcast every bucket-ordered parameter from `root` (initial parameter sync).
+  void broadcast_parameters(int root);
+  // Removes the autograd hooks (also done by the destructor).
+  void detach();
+
+ private:
+  struct BucketState {
+    BucketSpec spec;
+    std::vector<at::Tensor> views;      // per tensor: buffer slice shaped like the parameter
+    int64_t pending = 0;
+    bool launched = false;
+    std::vector<char> ready;            // per tensor in the bucket
+  };
+
+  void autograd_hook(int64_t param_index);
+  void launch_bucket(size_t b);
+  void launch_ready_buckets();
+  void finalize_backward();
+  void pack_into_bucket(BucketState& bs, const std::vector<int64_t>& local_ids, float scale);
+  void unpack_from_bucket(BucketState& bs);
+
+  std::vector<at::Tensor> params_;
+  std::vector<BucketState> buckets_;
+  std::vector<std::pair<int64_t, int64_t>> locator_;  // param -> (bucket, index inside bucket)
+  std::shared_ptr<Transport> transport_;
+  ReducerOptions opt_;
+  std::vector<std::pair<uintptr_t, std::shared_ptr<torch::autograd::Node>>> hooks_;
+
+  std::mutex mu_;
+  bool armed_ = false;
+  bool callback_queued_ = false;
+  size_t next_bucket_ = 0;
+  std::vector<int64_t> ready_order_, last_ready_order_;
+  int64_t n_syncs_ = 0, n_launches_ = 0, n_pack_launches_ = 0;
+};
+
+}  // namespace dpa

@@ -1,0 +1,3 @@
+from .adamw import FusedAdamW  # noqa: F401
+from .cross_entropy import SoftmaxCrossEntropy, softmax_cross_entropy  # noqa: F401
+from .linear import Linear, linear_bias_act  # noqa: F401

@@ -1,0 +1,150 @@
+"""Fused multi-tensor AdamW.
+
+Same update rule and defaults as ``torch.optim.AdamW`` -- which is what the reference
+trains with (``AdamW(model.parameters(), 0.0001)``, reference min_DDP.py:74,104) -- but one
+HIP launch updates up to 24 tensors, hyper-parameters and the step counter live in device
+memory (so a captured hipGraph keeps following a learning-rate schedule), and 16-bit
+parameters can carry fp32 master weights inside the optimizer.  Gradient clipping by global
+norm is folded in: the clip coefficient is computed on the device and applied inside the
+update kernel, with no host synchronisation.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+from torch.optim import Optimizer
+
+from .. import _ext
+
+
+class FusedAdamW(Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 master_weights: bool = False, max_grad_norm: Optional[float] = None):
+        if lr < 0.0:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if eps < 0.0:
+            raise ValueError(f"Invalid epsilon value: {eps}")
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f"Invalid beta parameters: {betas}")
+        if weight_decay < 0.0:
+            raise ValueError(f"Invalid weight_decay value: {weight_decay}")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.master_weights = bool(master_weights)
+        self.max_grad_norm = max_grad_norm
+        self._hparams: Dict[int, torch.Tensor] = {}       # group index -> device float32[8]
+        self._hparams_host: Dict[int, tuple] = {}
+        self._clip: Optional[Dict[str, torch.Tensor]] = None
+        self.last_grad_norm: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ state
+    def _init_state(self, p: torch.Tensor) -> dict:
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32)  # host-side mirror, kept for state_dict parity
+            st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+            if self.master_weights and p.dtype != torch.float32:
+                st["master"] = p.detach().to(torch.float32).clone()
+        return st
+
+    def _device_hparams(self, gi: int, group: dict, device: torch.device, step_before: int) -> torch.Tensor:
+        host = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"])
+        hp = self._hparams.get(gi)
+        if hp is None or hp.device != device:
+            vals = torch.tensor(list(host) + [0.0, 0.0, 0.0], dtype=torch.float32)
+            vals[5] = torch.tensor(step_before, dtype=torch.int32).view(torch.float32)
+            hp = vals.to(device)
+            self._hparams[gi] = hp
+            self._hparams_host[gi] = host
+        elif self._hparams_host[gi] != host:
+            hp[:5].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)
+            self._hparams_host[gi] = host
+        return hp
+
+    # ------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+
+        gpu_groups = []
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            if any(p.grad.is_sparse for p in ps):
+                raise RuntimeError("FusedAdamW does not support sparse gradients")
+            if ps[0].is_cuda:
+                gpu_groups.append((gi, group, ps))
+            else:
+                self._step_cpu(group, ps)
+
+        if not gpu_groups:
+            return loss
+        C = _ext.C()
+        grad_scale = None
+        if self.max_grad_norm is not None:
+            grad_scale = self._clip_coefficient(C, [p.grad for _, _, ps in gpu_groups for p in ps])
+        for gi, group, ps in gpu_groups:
+            states = [self._init_state(p) for p in ps]
+            step_before = int(states[0]["step"].item()) if gi not in self._hparams else 0
+            hp = self._device_hparams(gi, group, ps[0].device, step_before)
+            C.adamw_tick(hp)
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            C.adamw_step(ps, grads, [s["exp_avg"] for s in states], [s["exp_avg_sq"] for s in states],
+                         [s.get("master") for s in states], hp, grad_scale)
+            for s in states:
+                s["step"] += 1
+        return loss
+
+    def _clip_coefficient(self, C, grads: List[torch.Tensor]) -> torch.Tensor:
+        dev = grads[0].device
+        if self._clip is None or self._clip["sumsq"].device != dev:
+            z = lambda: torch.zeros(1, dtype=torch.float32, device=dev)
+            self._clip = {"sumsq": z(), "coef": z(), "norm": z()}
+        c = self._clip
+        c["sumsq"].zero_()
+        C.grad_sumsq([g if g.is_contiguous() else g.contiguous() for g in grads], c["sumsq"])
+        C.clip_coef(c["sumsq"], float(self.max_grad_norm), c["coef"], c["norm"])
+        self.last_grad_norm = c["norm"]
+        return c["coef"]
+
+    def _step_cpu(self, group: dict, ps: List[torch.Tensor]) -> None:
+        """Reference arithmetic on CPU tensors (the CPU oracle path): identical formula."""
+        lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
+        scale = 1.0
+        if self.max_grad_norm is not None:
+            norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in ps))
+            self.last_grad_norm = norm
+            scale = float(min(1.0, self.max_grad_norm / (norm + 1e-6)))
+        for p in ps:
+            st = self._init_state(p)
+            st["step"] += 1
+            t = int(st["step"].item())
+            g = p.grad.float() * scale
+            w = st.get("master", p if p.dtype == torch.float32 else p.float())
+            w.mul_(1 - lr * wd)
+            st["exp_avg"].lerp_(g, 1 - b1)
+            st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (st["exp_avg_sq"].sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+            w.addcdiv_(st["exp_avg"], denom, value=-lr / (1 - b1 ** t))
+            if w is not p:
+                p.copy_(w)
+
+    # ------------------------------------------------------------------ checkpointing
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # Device-side step counters are rebuilt from the restored per-parameter steps.
+        self._hparams.clear()
+        self._hparams_host.clear()
+        for st in self.state.values():
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+            for k in ("exp_avg", "exp_avg_sq", "master"):
+                if k in st:
+                    st[k] = st[k].to(torch.float32)

@@ -1,0 +1,308 @@
+"""Process-group state and collectives.
+
+Two data planes sit behind one API:
+
+``rccl``  GPU tensors.  The native ``RcclComm`` (``csrc/comm``): a communicator created
+          from an ``ncclUniqueId`` exchanged through our TCP store, bound to this rank's
+          device, with its own high-priority HIP stream.  ``"nccl"`` is accepted as an
+          alias because the reference asks for it by that name (distributed.py:63-64).
+``gloo``  CPU tensors.  c10d's gloo group, rendezvoused through our store; this is the
+          CPU oracle used by the multi-process tests.
+
+Every query and collective degrades to the single-process answer when no group is
+initialised, matching reference distributed.py:69-101,119-177.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.distributed as tdist
+
+from .. import _ext
+from .store import Store, TorchStoreAdapter, create_store_from_env
+
+# ncclRedOp_t values
+OP_SUM, OP_PROD, OP_MAX, OP_MIN, OP_AVG = 0, 1, 2, 3, 4
+_OP_NAMES = {"sum": OP_SUM, "prod": OP_PROD, "product": OP_PROD, "max": OP_MAX, "min": OP_MIN, "avg": OP_AVG, "mean": OP_AVG}
+
+
+@dataclass
+class _State:
+    rank: int
+    world_size: int
+    backend: str
+    store: Optional[Store]
+    comm: object = None          # _C.RcclComm for the rccl backend
+    device: Optional[torch.device] = None
+    owns_c10d: bool = False
+    timeout_s: float = 300.0
+    gen: int = 0
+
+
+_state: Optional[_State] = None
+
+
+def debug_sync() -> bool:
+    return os.environ.get("DIST_DEBUG_SYNC", "0") == "1"
+
+
+def _to_op_code(op) -> int:
+    """Accepts our string names, ``torch.distributed.ReduceOp`` members or raw ints."""
+    if isinstance(op, str):
+        try:
+            return _OP_NAMES[op.lower()]
+        except KeyError:
+            raise ValueError(f'"{op}" is an invalid reduce operation!') from None
+    if isinstance(op, int) and not isinstance(op, bool):
+        return op
+    for name, code in (("SUM", OP_SUM), ("PRODUCT", OP_PROD), ("MAX", OP_MAX), ("MIN", OP_MIN), ("AVG", OP_AVG)):
+        if op == getattr(tdist.ReduceOp, name):
+            return code
+    raise ValueError(f"unsupported reduce op {op!r}")
+
+
+def _to_c10d_op(code: int):
+    return {OP_SUM: tdist.ReduceOp.SUM, OP_PROD: tdist.ReduceOp.PRODUCT, OP_MAX: tdist.ReduceOp.MAX, OP_MIN: tdist.ReduceOp.MIN, OP_AVG: tdist.ReduceOp.AVG}[code]
+
+
+# ------------------------------------------------------------------------------ queries
+def is_initialized() -> bool:
+    return _state is not None
+
+
+def get_rank() -> int:
+    return 0 if _state is None else _state.rank
+
+
+def get_world_size() -> int:
+    return 1 if _state is None else _state.world_size
+
+
+def get_backend() -> Optional[str]:
+    return None if _state is None else _state.backend
+
+
+def get_store() -> Optional[Store]:
+    return None if _state is None else _state.store
+
+
+def get_comm():
+    return None if _state is None else _state.comm
+
+
+def local_device_index(rank: Optional[int] = None) -> int:
+    """Device index this rank should use.
+
+    Our launcher rotates ``HIP_VISIBLE_DEVICES`` so the rank's GPU is index 0 and says so
+    in ``DIST_LOCAL_DEVICE``; under torchrun it is ``LOCAL_RANK``; otherwise the rank
+    itself (reference distributed.py:88-91), wrapped into the visible range.
+    """
+    v = os.environ.get("DIST_LOCAL_DEVICE")
+    if v not in (None, ""):
+        return int(v)
+    v = os.environ.get("LOCAL_RANK")
+    if v not in (None, ""):
+        idx = int(v)
+    else:
+        idx = get_rank() if rank is None else rank
+    n = torch.cuda.device_count()
+    return idx % n if n > 0 else 0
+
+
+def get_device() -> torch.device:
+    if torch.cuda.is_available():
+        if _state is not None and _state.device is not None and _state.device.type == "cuda":
+            return _state.device
+        return torch.device(f"cuda:{local_device_index()}")
+    return torch.device("cpu")
+
+
+# ------------------------------------------------------------------------------ lifecycle
+def init_process_group(rank: int, world_size: int, backend: Optional[str] = None, *, timeout_s: Optional[float] = None, store: Optional[Store] = None) -> None:
+    global _state
+    if _state is not None:
+        raise RuntimeError("process group is already initialised")
+    if backend is None:
+        backend = "rccl" if torch.cuda.is_available() else "gloo"
+    backend = {"nccl": "rccl"}.get(backend.lower(), backend.lower())
+    if backend not in ("rccl", "gloo"):
+        raise ValueError(f"unknown backend '{backend}' (rccl | nccl | gloo)")
+    world_size = max(int(world_size), 1)
+    rank = int(rank)
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} out of range for world size {world_size}")
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("DIST_TIMEOUT_S", "300"))
+
+    st = store if store is not None else create_store_from_env(rank, world_size, timeout=timeout_s)
+    state = _State(rank=rank, world_size=world_size, backend=backend, store=st, timeout_s=timeout_s)
+    # Every rank bumps its own counter, so the n-th init on one store gets generation n on
+    # all ranks and never reads keys left behind by an earlier group.
+    gen = st.add(f"pg/gen/{rank}", 1)
+    state.gen = gen
+
+    if backend == "rccl":
+        if not torch.cuda.is_available():
+            raise RuntimeError("backend 'rccl' needs a GPU; use backend='gloo' on CPU")
+        C = _ext.C()
+        dev = torch.device(f"cuda:{local_device_index(rank)}")
+        torch.cuda.set_device(dev)  # explicit binding; the reference leaves this to NCCL's inference
+        state.device = dev
+        key = f"rccl/uid/{gen}"
+        if rank == 0:
+            st.set(key, C.RcclComm.unique_id())
+        uid = st.get(key, timeout_s)
+        # Communicator is created eagerly so that iteration 0 does not pay for it.
+        state.comm = C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0)
+    else:
+        state.device = torch.device("cpu") if not torch.cuda.is_available() else torch.device(f"cuda:{local_device_index(rank)}")
+        if not tdist.is_initialized():
+            tdist.init_process_group(
+                "gloo", store=TorchStoreAdapter(st, prefix=f"c10d/{gen}/"), rank=rank, world_size=world_size,
+                timeout=datetime.timedelta(seconds=timeout_s),
+            )
+            state.owns_c10d = True
+    _state = state
+    # Everyone has joined before anyone proceeds; also surfaces a dead rank at start-up.
+    st.barrier(f"init/{gen}", world_size, timeout_s)
+
+
+def destroy_process_group() -> None:
+    global _state
+    st = _state
+    if st is None:
+        return
+    _state = None
+    try:
+        if st.comm is not None:
+            st.comm.destroy()
+        if st.owns_c10d and tdist.is_initialized():
+            tdist.destroy_process_group()
+    finally:
+        if st.store is not None:
+            # The hosting rank keeps the server up until every rank has checked out.
+            try:
+                key = f"shutdown/{st.gen}"
+                st.store.add(key, 1)
+                if st.store.is_host:
+                    import time
+
+                    deadline = time.time() + 10.0
+                    while time.time() < deadline and int(st.store.add(key, 0)) < st.world_size:
+                        time.sleep(0.005)
+            except Exception:
+                pass
+            st.store.close()
+
+
+# ------------------------------------------------------------------------------ helpers
+def _stage_for_rccl(t: torch.Tensor):
+    """RCCL needs device memory; a CPU tensor is round-tripped through the rank's GPU."""
+    if t.is_cuda:
+        return (t if t.is_contiguous() else t.contiguous()), None
+    return t.to(_state.device).contiguous(), t
+
+
+def _finish(staged: torch.Tensor, original_cpu: Optional[torch.Tensor], user: torch.Tensor) -> None:
+    if original_cpu is not None:
+        original_cpu.copy_(staged)
+    elif staged.data_ptr() != user.data_ptr():
+        user.copy_(staged)
+    if debug_sync() and staged.is_cuda:
+        torch.cuda.synchronize(staged.device)
+
+
+# ------------------------------------------------------------------------------ collectives
+def all_reduce(t: torch.Tensor, op=OP_SUM) -> torch.Tensor:
+    code = _to_op_code(op)
+    if _state is None or _state.world_size == 1:
+        return t
+    if _state.backend == "rccl":
+        s, cpu = _stage_for_rccl(t)
+        _state.comm.all_reduce(s, code)
+        _finish(s, cpu, t)
+    else:
+        if code == OP_AVG:  # gloo has no AVG
+            tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+            t /= _state.world_size
+        else:
+            tdist.all_reduce(t, op=_to_c10d_op(code))
+    return t
+
+
+def reduce(t: torch.Tensor, dst: int = 0, op=OP_SUM) -> torch.Tensor:
+    code = _to_op_code(op)
+    if _state is None or _state.world_size == 1:
+        return t
+    if _state.backend == "rccl":
+        s, cpu = _stage_for_rccl(t)
+        _state.comm.reduce(s, int(dst), code)
+        _finish(s, cpu, t)
+    else:
+        tdist.reduce(t, dst=dst, op=_to_c10d_op(code))
+    return t
+
+
+def broadcast(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if _state is None or _state.world_size == 1:
+        return t
+    if _state.backend == "rccl":
+        s, cpu = _stage_for_rccl(t)
+        _state.comm.broadcast(s, int(src))
+        _finish(s, cpu, t)
+    else:
+        tdist.broadcast(t, src)
+    return t
+
+
+def gather(t: torch.Tensor, dst: int = 0) -> List[torch.Tensor]:
+    """List of ``world_size`` tensors in rank order; real data on ``dst`` only, zeros elsewhere
+    (reference distributed.py:147-160)."""
+    if _state is None or _state.world_size == 1:
+        return [t]
+    w = _state.world_size
+    if _state.backend == "rccl":
+        s, cpu = _stage_for_rccl(t)
+        # One contiguous [world, ...] slab filled by a single ncclGather; rows are returned as views.
+        out = torch.zeros((w,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+        _state.comm.gather(s, out if _state.rank == dst else None, int(dst))
+        if debug_sync():
+            torch.cuda.synchronize(s.device)
+        if cpu is not None:
+            out = out.cpu()
+        return list(out.unbind(0))
+    outs = [torch.zeros_like(t) for _ in range(w)]
+    if _state.rank == dst:
+        tdist.gather(t, gather_list=outs, dst=dst)
+    else:
+        tdist.gather(t, dst=dst)
+    return outs
+
+
+def all_gather(t: torch.Tensor) -> List[torch.Tensor]:
+    if _state is None or _state.world_size == 1:
+        return [t]
+    w = _state.world_size
+    if _state.backend == "rccl":
+        s, cpu = _stage_for_rccl(t)
+        out = torch.empty((w,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+        _state.comm.all_gather(s, out)
+        if cpu is not None:
+            out = out.cpu()
+        return list(out.unbind(0))
+    outs = [torch.empty_like(t) for _ in range(w)]
+    tdist.all_gather(outs, t)
+    return outs
+
+
+def barrier() -> None:
+    if _state is None or _state.world_size == 1:
+        return
+    if _state.backend == "rccl":
+        _state.comm.barrier()
+    else:
+        tdist.barrier()

@@ -37,7 +37,8 @@ PYBIND11_MODULE(_C, m) {
       .def("wait_slot", &RcclComm::wait_slot)
       .def("wait_all_slots", &RcclComm::wait_all_slots)
       .def("synchronize_comm_stream", &RcclComm::synchronize_comm_stream, py::call_guard<py::gil_scoped_release>())
-      .def("comm_stream_handle", [](const RcclComm& c) { return reinterpret_cast<uintptr_t>(c.comm_stream()); })
+      .def("comm_stream_handle", [](RcclComm& c) { return reinterpret_cast<uintptr_t>(c.comm_stream()); })
+      .def("set_comm_stream", &RcclComm::set_comm_stream, py::arg("handle"))
       .def("group_start", &RcclComm::group_start)
       .def("group_end", &RcclComm::group_end)
       .def("num_async_ops", &RcclComm::num_async_ops)

@@ -77,11 +77,13 @@ RcclComm::RcclComm(const std::string& uid, int rank, int world, int device)
   ncclUniqueId id;
   std::memcpy(&id, uid.data(), sizeof(id));
   DPA_HIP_CHECK(hipSetDevice(device_));
+  // The communication stream (and torch's stream pools) must exist BEFORE the communicator
+  // is created.  Measured on MI355X / ROCm 7.0 runtime: a stream created after ncclCommInitRank
+  // that exchanges events with the default stream stalls forever (probe: tools/diag_events.cpp),
+  // while a stream created ahead of it works for any number of in-flight operations.
+  (void)c10::hip::getStreamFromPool(/*isHighPriority=*/false, static_cast<c10::DeviceIndex>(device_));
+  ensure_comm_stream();
   DPA_NCCL_CHECK(ncclCommInitRank(&comm_, world_, id, rank_));
-  int lo = 0, hi = 0;
-  DPA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi is the numerically lowest = highest priority
-  DPA_HIP_CHECK(hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, hi));
-  DPA_HIP_CHECK(hipEventCreateWithFlags(&fence_event_, hipEventDisableTiming));
   barrier_scratch_ = at::zeros({1}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, device_));
 }
 
@@ -105,10 +107,10 @@ void RcclComm::destroy() {
   for (hipEvent_t e : slot_events_)
     if (e) (void)hipEventDestroy(e);
   slot_events_.clear();
-  if (fence_event_) (void)hipEventDestroy(fence_event_);
-  fence_event_ = nullptr;
-  if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
-  comm_stream_ = nullptr;
+  for (hipEvent_t e : fence_events_)
+    if (e) (void)hipEventDestroy(e);
+  fence_events_.clear();
+  comm_stream_ = nullptr;  // owned by torch's stream pool
   barrier_scratch_ = at::Tensor();
 }
 
@@ -194,24 +196,41 @@ void RcclComm::barrier() {
   DPA_HIP_CHECK(hipStreamSynchronize(s));
 }
 
-hipEvent_t& RcclComm::slot_event(int slot) {
+// Prepares slot `slot` for a new operation: events exist, and a previous operation on the same
+// slot that nobody waited for has finished.  An event is never re-recorded while a stream may
+// still be waiting on its previous record: every slot owns its own fence and completion event.
+void RcclComm::ensure_comm_stream() {
+  // High-priority stream from torch's pool (non-blocking with respect to the default stream), so
+  // RCCL kernels are scheduled ahead of queued backward kernels.  Taken on first use unless the
+  // caller installed one with set_comm_stream().
+  if (!comm_stream_)
+    comm_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/true, static_cast<c10::DeviceIndex>(device_)).stream();
+}
+
+void RcclComm::set_comm_stream(uintptr_t handle) { comm_stream_ = reinterpret_cast<hipStream_t>(handle); }
+
+void RcclComm::begin_slot(int slot) {
   if (slot < 0) throw std::runtime_error("RcclComm: negative slot");
-  if (static_cast<size_t>(slot) >= slot_events_.size()) {
-    slot_events_.resize(static_cast<size_t>(slot) + 1, nullptr);
-    slot_pending_.resize(static_cast<size_t>(slot) + 1, 0);
+  ensure_comm_stream();
+  const size_t s = static_cast<size_t>(slot);
+  if (s >= slot_events_.size()) {
+    slot_events_.resize(s + 1, nullptr);
+    fence_events_.resize(s + 1, nullptr);
+    slot_pending_.resize(s + 1, 0);
   }
-  if (!slot_events_[static_cast<size_t>(slot)])
-    DPA_HIP_CHECK(hipEventCreateWithFlags(&slot_events_[static_cast<size_t>(slot)], hipEventDisableTiming));
-  return slot_events_[static_cast<size_t>(slot)];
+  if (!slot_events_[s]) DPA_HIP_CHECK(hipEventCreateWithFlags(&slot_events_[s], hipEventDisableTiming));
+  if (!fence_events_[s]) DPA_HIP_CHECK(hipEventCreateWithFlags(&fence_events_[s], hipEventDisableTiming));
+  if (slot_pending_[s]) DPA_HIP_CHECK(hipEventSynchronize(slot_events_[s]));
 }
 
 void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
   check_tensor(t);
   DeviceGuard g(device_);
-  hipEvent_t& done = slot_event(slot);
+  begin_slot(slot);
+  hipEvent_t done = slot_events_[static_cast<size_t>(slot)], fence = fence_events_[static_cast<size_t>(slot)];
   // Fence: the bucket was filled by kernels queued on the current stream.
-  DPA_HIP_CHECK(hipEventRecord(fence_event_, current_stream(device_)));
-  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence_event_, 0));
+  DPA_HIP_CHECK(hipEventRecord(fence, current_stream(device_)));
+  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence, 0));
   if (t.numel() > 0)
     DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                  static_cast<ncclRedOp_t>(op), comm_, comm_stream_));
@@ -223,9 +242,10 @@ void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
 void RcclComm::broadcast_async(at::Tensor t, int root, int slot) {
   check_tensor(t);
   DeviceGuard g(device_);
-  hipEvent_t& done = slot_event(slot);
-  DPA_HIP_CHECK(hipEventRecord(fence_event_, current_stream(device_)));
-  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence_event_, 0));
+  begin_slot(slot);
+  hipEvent_t done = slot_events_[static_cast<size_t>(slot)], fence = fence_events_[static_cast<size_t>(slot)];
+  DPA_HIP_CHECK(hipEventRecord(fence, current_stream(device_)));
+  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence, 0));
   if (t.numel() > 0)
     DPA_NCCL_CHECK(ncclBroadcast(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                  root, comm_, comm_stream_));

@@ -52,7 +52,12 @@ class RcclComm {
   void wait_slot(int slot);         // current stream waits for slot's completion event
   void wait_all_slots();            // ... for every slot used since the last call
   void synchronize_comm_stream();   // host waits (debug / teardown)
-  hipStream_t comm_stream() const { return comm_stream_; }
+  hipStream_t comm_stream() {
+    ensure_comm_stream();
+    return comm_stream_;
+  }
+  // Use an existing stream (e.g. a torch.cuda.Stream created by the caller) for the async ops.
+  void set_comm_stream(uintptr_t handle);
 
   void group_start();
   void group_end();
@@ -64,14 +69,15 @@ class RcclComm {
   int64_t num_async_ops() const { return n_async_; }
 
  private:
-  hipEvent_t& slot_event(int slot);
+  void begin_slot(int slot);
+  void ensure_comm_stream();
   void check_tensor(const at::Tensor& t) const;
 
   ncclComm_t comm_ = nullptr;
   int rank_, world_, device_;
   hipStream_t comm_stream_ = nullptr;
-  hipEvent_t fence_event_ = nullptr;
-  std::vector<hipEvent_t> slot_events_;
+  std::vector<hipEvent_t> slot_events_;   // completion of the operation on the comm stream
+  std::vector<hipEvent_t> fence_events_;  // "inputs are ready" on the stream that produced them
   std::vector<char> slot_pending_;
   at::Tensor barrier_scratch_;
   int64_t n_async_ = 0;

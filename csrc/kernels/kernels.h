@@ -57,8 +57,9 @@ void launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* no
                       hipStream_t stream);
 
 // ------------------------------------------------------------------ softmax cross-entropy
-// logits: [N, ld] with the first C columns valid.  Per row: loss (0 for ignored rows),
-// log-sum-exp, and a correct flag (argmax == target, lowest index wins ties).
+// logits: [N, ld] with the first C columns valid.  Per row: loss (0 for ignored rows), the
+// pair (row max, log of the sum of exp(x - max)) in row_lse[2r], row_lse[2r+1], and a correct
+// flag (argmax == target, lowest index wins ties).
 void launch_xent_fwd(const void* logits, int dtype, const long long* targets, long long N,
                      long long C, long long ld, long long ignore_index, float* row_loss,
                      float* row_lse, unsigned char* correct, hipStream_t stream);

@@ -44,10 +44,13 @@ __global__ __launch_bounds__(256) void xent_fwd_small_kernel(const typename TR::
   }
   float s = 0.f;
   for (int j = 0; j < C; ++j) s += __expf(TR::to_f32(row[j]) - mx);
-  const float lse = mx + __logf(s);
+  // max and log-sum are kept apart: (max - x_t) + log(sum) stays accurate when |logits| is
+  // large, where max + log(sum) would round at the magnitude of the logits.
+  const float ls = __logf(s);
   const bool ignored = (tgt == ignore_index) || tgt < 0 || tgt >= C;
-  row_lse[r] = lse;
-  row_loss[r] = ignored ? 0.f : lse - xt;
+  row_lse[2 * r] = mx;
+  row_lse[2 * r + 1] = ls;
+  row_loss[r] = ignored ? 0.f : (mx - xt) + ls;
   correct[r] = (!ignored && arg == tgt) ? 1 : 0;
 }
 
@@ -63,11 +66,11 @@ __global__ __launch_bounds__(256) void xent_bwd_small_kernel(const typename TR::
   float g = grad_out[0];
   if (mean) g /= fmaxf(metrics[2], 1.f);
   if (ignored) g = 0.f;
-  const float lse = row_lse[r];
+  const float mx = row_lse[2 * r], ls = row_lse[2 * r + 1];
   const typename TR::T* row = logits + r * ld;
   typename TR::T* out = dlogits + r * ld;
   for (int j = 0; j < C; ++j) {
-    const float p = __expf(TR::to_f32(row[j]) - lse);
+    const float p = __expf((TR::to_f32(row[j]) - mx) - ls);
     out[j] = TR::from_f32((p - (j == tgt ? 1.f : 0.f)) * g);
   }
   for (long long j = C; j < ld; ++j) out[j] = TR::from_f32(0.f);
@@ -175,10 +178,11 @@ __global__ __launch_bounds__(THREADS) void xent_fwd_row_kernel(const typename TR
       M = nm;
       S = sa + sb;
     }
-    const float lse = M + __logf(S);
+    const float ls = __logf(S);
     const bool ignored = (tgt == ignore_index) || tgt < 0 || tgt >= C;
-    row_lse[r] = lse;
-    row_loss[r] = ignored ? 0.f : lse - TR::to_f32(row[tgt]);
+    row_lse[2 * r] = M;
+    row_lse[2 * r + 1] = ls;
+    row_loss[r] = ignored ? 0.f : (M - TR::to_f32(row[tgt])) + ls;
     correct[r] = (!ignored && A == tgt) ? 1 : 0;
   }
 }
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void xent_bwd_row_kernel(const typename TR
   float g = grad_out[0];
   if (mean) g /= fmaxf(metrics[2], 1.f);
   if (ignored) g = 0.f;
-  const float lse = row_lse[r];
+  const float mx = row_lse[2 * r], ls = row_lse[2 * r + 1];
   const typename TR::T* row = logits + r * ld;
   typename TR::T* out = dlogits + r * ld;
   const bool aligned = ((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
@@ -205,12 +209,12 @@ __global__ __launch_bounds__(THREADS) void xent_bwd_row_kernel(const typename TR
     load_as_f32<TR, V>(row + i * V, a);
     const long long j0 = i * V;
 #pragma unroll
-    for (int j = 0; j < V; ++j) a[j] = (__expf(a[j] - lse) - ((j0 + j) == tgt ? 1.f : 0.f)) * g;
+    for (int j = 0; j < V; ++j) a[j] = (__expf((a[j] - mx) - ls) - ((j0 + j) == tgt ? 1.f : 0.f)) * g;
     store_from_f32<TR, V>(out + i * V, a);
   }
   for (long long j = nvec * V + threadIdx.x; j < ld; j += THREADS) {
     float d = 0.f;
-    if (j < C) d = (__expf(TR::to_f32(row[j]) - lse) - (j == tgt ? 1.f : 0.f)) * g;
+    if (j < C) d = (__expf((TR::to_f32(row[j]) - mx) - ls) - (j == tgt ? 1.f : 0.f)) * g;
     out[j] = TR::from_f32(d);
   }
 }

@@ -211,7 +211,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> xent_forward(Tensor logits, Tensor ta
   TORCH_CHECK(C <= ld, "n_classes exceeds the logits width");
   TORCH_CHECK(N < (1ll << 31), "too many rows");
   auto fopt = logits.options().dtype(at::kFloat);
-  Tensor row_loss = at::empty({N}, fopt), row_lse = at::empty({N}, fopt);
+  Tensor row_loss = at::empty({N}, fopt), row_lse = at::empty({N, 2}, fopt);
   Tensor correct = at::empty({N}, logits.options().dtype(at::kBool));
   Tensor metrics = at::empty({4}, fopt);
   DevGuard g(logits);
@@ -232,7 +232,7 @@ Tensor xent_backward(Tensor logits, Tensor targets, Tensor row_lse, Tensor grad_
   check_gpu(row_lse, "row_lse");
   check_gpu(grad_out, "grad_out");
   check_gpu(metrics, "metrics");
-  TORCH_CHECK(logits.dim() == 2 && targets.numel() == logits.size(0) && row_lse.numel() == logits.size(0), "xent_backward: shape mismatch");
+  TORCH_CHECK(logits.dim() == 2 && targets.numel() == logits.size(0) && row_lse.numel() == 2 * logits.size(0), "xent_backward: shape mismatch");
   TORCH_CHECK(targets.scalar_type() == at::kLong && row_lse.scalar_type() == at::kFloat && metrics.scalar_type() == at::kFloat &&
                   metrics.numel() >= 4, "xent_backward: dtype mismatch");
   TORCH_CHECK(grad_out.scalar_type() == at::kFloat && grad_out.numel() == 1, "xent_backward: grad_out must be a float32 scalar");

@@ -1,0 +1,169 @@
+"""GPT-2 (decoder-only transformer) for the data-parallel benchmark configuration
+"GPT-2 small, synthetic 1024-token sequences, bf16".
+
+The reference ships only a two-layer toy model (reference min_DDP.py:41-49); this model
+family exists because the framework's throughput bar is defined on it.  Hot ops map to the
+native kernels: layer norm, the MLP up-projection with fused bias + GELU epilogue, the loss
+(fused softmax cross-entropy + accuracy over a vocabulary padded to a multiple of 64 so
+every logits row is 16-byte aligned, gradient written in place over the logits), and the
+optimizer (FusedAdamW).  Attention uses torch's fused scaled-dot-product kernel.
+
+``linear_impl``: ``"native"`` routes every projection through the hand-written MFMA GEMM,
+``"library"`` through the vendor GEMM behind ``F.linear`` (plain GEMMs without a fused
+epilogue), ``"auto"`` keeps the native kernel only where it fuses an epilogue.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops.cross_entropy import softmax_cross_entropy
+from ..ops.layernorm import LayerNorm
+from ..ops.linear import linear_bias_act
+
+
+@dataclass
+class GPT2Config:
+    block_size: int = 1024
+    vocab_size: int = 50257
+    n_layer: int = 12
+    n_head: int = 12
+    n_embd: int = 768
+    bias: bool = True
+    vocab_pad_multiple: int = 64
+    linear_impl: str = "auto"     # native | library | auto
+    inplace_loss_backward: bool = True
+
+    @property
+    def padded_vocab_size(self) -> int:
+        m = self.vocab_pad_multiple
+        return (self.vocab_size + m - 1) // m * m
+
+    @staticmethod
+    def small(**kw) -> "GPT2Config":
+        return GPT2Config(n_layer=12, n_head=12, n_embd=768, **kw)
+
+    @staticmethod
+    def medium(**kw) -> "GPT2Config":
+        return GPT2Config(n_layer=24, n_head=16, n_embd=1024, **kw)
+
+
+class _Proj(nn.Linear):
+    """Projection whose GEMM implementation is chosen by the model config."""
+
+    def __init__(self, in_f, out_f, bias, impl: str, act: Optional[str] = None):
+        super().__init__(in_f, out_f, bias=bias)
+        self.impl = impl
+        self.act = act
+
+    def forward(self, x):
+        use_native = self.impl == "native" or (self.impl == "auto" and self.act is not None)
+        if use_native and x.is_cuda:
+            return linear_bias_act(x, self.weight, self.bias, self.act)
+        y = F.linear(x, self.weight, self.bias)
+        if self.act == "gelu":
+            y = F.gelu(y)
+        elif self.act == "relu":
+            y = F.relu(y)
+        return y
+
+
+class CausalSelfAttention(nn.Module):
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        assert cfg.n_embd % cfg.n_head == 0
+        self.n_head = cfg.n_head
+        self.c_attn = _Proj(cfg.n_embd, 3 * cfg.n_embd, cfg.bias, cfg.linear_impl)
+        self.c_proj = _Proj(cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
+
+    def forward(self, x):
+        B, T, Cd = x.shape
+        q, k, v = self.c_attn(x).split(Cd, dim=2)
+        hd = Cd // self.n_head
+        q = q.view(B, T, self.n_head, hd).transpose(1, 2)
+        k = k.view(B, T, self.n_head, hd).transpose(1, 2)
+        v = v.view(B, T, self.n_head, hd).transpose(1, 2)
+        y = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        y = y.transpose(1, 2).reshape(B, T, Cd)
+        return self.c_proj(y)
+
+
+class MLP(nn.Module):
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        self.c_fc = _Proj(cfg.n_embd, 4 * cfg.n_embd, cfg.bias, cfg.linear_impl, act="gelu")
+        self.c_proj = _Proj(4 * cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
+
+    def forward(self, x):
+        return self.c_proj(self.c_fc(x))
+
+
+class Block(nn.Module):
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        self.ln_1 = LayerNorm(cfg.n_embd)
+        self.attn = CausalSelfAttention(cfg)
+        self.ln_2 = LayerNorm(cfg.n_embd)
+        self.mlp = MLP(cfg)
+
+    def forward(self, x):
+        x = x + self.attn(self.ln_1(x))
+        x = x + self.mlp(self.ln_2(x))
+        return x
+
+
+class GPT2(nn.Module):
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        self.cfg = cfg
+        V = cfg.padded_vocab_size
+        self.wte = nn.Embedding(V, cfg.n_embd)
+        self.wpe = nn.Embedding(cfg.block_size, cfg.n_embd)
+        self.h = nn.ModuleList([Block(cfg) for _ in range(cfg.n_layer)])
+        self.ln_f = LayerNorm(cfg.n_embd)
+        # lm_head shares the token-embedding matrix (weight tying), so it has no parameter of its own
+        self.apply(self._init_weights)
+        for name, p in self.named_parameters():
+            if name.endswith("c_proj.weight"):
+                nn.init.normal_(p, mean=0.0, std=0.02 / math.sqrt(2 * cfg.n_layer))
+        self.last_correct = None
+        self.last_metrics = None
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, mean=0.0, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, mean=0.0, std=0.02)
+
+    def num_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    def flops_per_token(self, seq_len: int) -> float:
+        """Training FLOPs per token: 6 * (non-embedding params + lm_head) + attention."""
+        cfg = self.cfg
+        n = sum(p.numel() for name, p in self.named_parameters() if not name.startswith("wpe"))
+        return 6.0 * n + 12.0 * cfg.n_layer * cfg.n_embd * seq_len
+
+    def forward(self, idx: torch.Tensor, targets: Optional[torch.Tensor] = None):
+        B, T = idx.shape
+        assert T <= self.cfg.block_size
+        pos = torch.arange(T, device=idx.device)
+        x = self.wte(idx) + self.wpe(pos)
+        for blk in self.h:
+            x = blk(x)
+        x = self.ln_f(x)
+        if targets is None:
+            return F.linear(x[:, -1:, :], self.wte.weight)[..., : self.cfg.vocab_size]
+        logits = F.linear(x, self.wte.weight)  # [B, T, padded vocab]: plain GEMM, vendor library
+        r = softmax_cross_entropy(logits.view(B * T, -1), targets.reshape(-1), n_classes=self.cfg.vocab_size,
+                                  inplace_backward=self.cfg.inplace_loss_backward)
+        self.last_correct, self.last_metrics = r.correct, r.metrics
+        return r.loss

@@ -1,0 +1,340 @@
+"""Numerics of every HIP kernel against plain PyTorch references (fp32 / fp64 math on the
+same inputs).  Shape grids include the reference model's degenerate layers (K = 1, N = 4),
+sizes that are not multiples of any tile, single rows, and extreme logits."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def C():
+    from distributed_pytorch_amd import _ext
+
+    return _ext.C()
+
+
+def tol(dtype):
+    return dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- pack
+@pytest.mark.parametrize("src_dt,dst_dt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                            (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+def test_multi_copy_scale(src_dt, dst_dt):
+    torch.manual_seed(0)
+    sizes = [1, 7, 8, 63, 4096, 8192, 8193, 100003] + [33] * 40  # > 32 tensors: several launches
+    srcs = [torch.randn(n, device=DEV).to(src_dt) for n in sizes]
+    flat = torch.full((sum((n + 31) // 32 * 32 for n in sizes),), 7.0, device=DEV, dtype=dst_dt)
+    dsts, off = [], 0
+    for n in sizes:
+        dsts.append(flat.narrow(0, off, n))
+        off += (n + 31) // 32 * 32
+    C().multi_copy_scale(srcs, dsts, 0.25)
+    for s, d in zip(srcs, dsts):
+        ref = (s.float() * 0.25).to(dst_dt)
+        assert torch.equal(d, ref)
+    # padding between tensors is untouched
+    assert flat[sizes[0]].item() == 7.0
+
+
+def test_multi_copy_unaligned_views():
+    base = torch.randn(10001, device=DEV)
+    out = torch.zeros(10001, device=DEV)
+    C().multi_copy_scale([base[1:5000], base[5003:]], [out[3:5002], out[5003:]], 2.0)
+    assert torch.equal(out[3:5002], base[1:5000] * 2)
+    assert torch.equal(out[5003:], base[5003:] * 2)
+    assert out[5002].item() == 0.0 and out[:3].abs().sum().item() == 0.0
+
+
+def test_scale_inplace():
+    for dt in (torch.float32, torch.bfloat16):
+        t = torch.randn(100001, device=DEV).to(dt)
+        ref = (t.float() * 0.125).to(dt)
+        C().scale_inplace(t, 0.125)
+        assert torch.equal(t, ref)
+
+
+# ----------------------------------------------------------------------------- AdamW
+@pytest.mark.parametrize("wd", [0.01, 0.0])
+def test_fused_adamw_matches_torch_fp32(wd):
+    from distributed_pytorch_amd.ops import FusedAdamW
+
+    torch.manual_seed(1)
+    shapes = [(4096, 1), (4096,), (4, 4096), (4,), (257, 33), (1,)] + [(17,)] * 30
+    ref_p = [torch.randn(s, dtype=torch.float64) for s in shapes]
+    my_p = [p.clone().float().to(DEV).requires_grad_() for p in ref_p]
+    ref_p = [p.requires_grad_() for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=1e-2, weight_decay=wd)
+    mine = FusedAdamW(my_p, lr=1e-2, weight_decay=wd)
+    for step in range(12):
+        for rp, mp in zip(ref_p, my_p):
+            g = torch.randn(rp.shape, dtype=torch.float64)
+            rp.grad = g
+            mp.grad = g.float().to(DEV)
+        ref.step()
+        mine.step()
+    for rp, mp in zip(ref_p, my_p):
+        torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_fused_adamw_bf16_master_weights_and_lr_change():
+    from distributed_pytorch_amd.ops import FusedAdamW
+
+    torch.manual_seed(2)
+    w0 = torch.randn(1000, 64)
+    ref_p = w0.clone().double().requires_grad_()
+    my_p = w0.clone().to(DEV).bfloat16().requires_grad_()
+    ref_p.data = my_p.detach().cpu().double()  # same starting point after bf16 rounding
+    ref = torch.optim.AdamW([ref_p], lr=1e-3)
+    mine = FusedAdamW([my_p], lr=1e-3, master_weights=True)
+    for step in range(8):
+        if step == 4:  # learning-rate schedule must reach the device-side hyper-parameters
+            for o in (ref, mine):
+                o.param_groups[0]["lr"] = 5e-4
+        g = torch.randn(1000, 64).bfloat16()
+        ref_p.grad = g.double()
+        my_p.grad = g.to(DEV)
+        ref.step()
+        mine.step()
+    master = mine.state[my_p]["master"]
+    torch.testing.assert_close(master.cpu().double(), ref_p.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(my_p.detach().cpu().double(), ref_p.detach(), rtol=1e-2, atol=1e-2)
+
+
+def test_fused_adamw_clipping():
+    from distributed_pytorch_amd.ops import FusedAdamW
+
+    torch.manual_seed(3)
+    ref_p = [torch.randn(300, 7, dtype=torch.float64).requires_grad_(), torch.randn(50, dtype=torch.float64).requires_grad_()]
+    my_p = [p.detach().clone().float().to(DEV).requires_grad_() for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=1e-2)
+    mine = FusedAdamW(my_p, lr=1e-2, max_grad_norm=1.0)
+    for _ in range(3):
+        for rp, mp in zip(ref_p, my_p):
+            g = torch.randn(rp.shape, dtype=torch.float64) * 3
+            rp.grad = g
+            mp.grad = g.float().to(DEV)
+        n = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+        ref.step()
+        mine.step()
+        torch.testing.assert_close(mine.last_grad_norm.cpu().double().squeeze(), n, rtol=1e-5, atol=1e-6)
+    for rp, mp in zip(ref_p, my_p):
+        torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
+
+
+# ----------------------------------------------------------------------------- softmax cross-entropy
+@pytest.mark.parametrize("N,Cc,ld", [(8, 4, 4), (1, 4, 4), (1000, 4, 4), (37, 10, 10), (64, 1000, 1000), (5, 1001, 1001),
+                                     (33, 5000, 5000), (16, 50257, 50304), (3, 50257, 50257)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_xent_forward_backward(N, Cc, ld, dtype):
+    from distributed_pytorch_amd.ops import softmax_cross_entropy
+
+    torch.manual_seed(N * 31 + Cc)
+    logits = (torch.randn(N, ld, device=DEV) * 3).to(dtype)
+    targets = torch.randint(0, Cc, (N,), device=DEV)
+    lg = logits.clone().requires_grad_()
+    res = softmax_cross_entropy(lg, targets, n_classes=Cc)
+    (res.loss * 1.7).backward()
+
+    ref_in = logits[:, :Cc].double().requires_grad_()
+    ref_loss = F.cross_entropy(ref_in, targets)
+    (ref_loss * 1.7).backward()
+    torch.testing.assert_close(res.loss.double(), ref_loss.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(res.correct, ref_in.argmax(1) == targets)
+    assert res.metrics[1].item() == float((ref_in.argmax(1) == targets).sum())
+    assert res.metrics[2].item() == N
+    g = lg.grad.double()
+    gt = dict(rtol=1e-4, atol=1e-7) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-4)
+    torch.testing.assert_close(g[:, :Cc], ref_in.grad, **gt)
+    if ld > Cc:
+        assert torch.count_nonzero(g[:, Cc:]) == 0
+
+
+def test_xent_extreme_logits_ties_and_ignore_index():
+    from distributed_pytorch_amd.ops import softmax_cross_entropy
+
+    for Cc in (4, 300, 9000):
+        logits = torch.zeros(6, Cc, device=DEV)
+        logits[0, 1] = 1e4          # would overflow exp() without max subtraction
+        logits[1, :] = -1e4
+        logits[2, 2] = 5.0
+        logits[2, 3] = 5.0          # tie: lowest index wins
+        logits[3, Cc - 1] = 80.0
+        targets = torch.tensor([1, 0, 2, Cc - 1, -100, 3], device=DEV)
+        lg = logits.clone().requires_grad_()
+        r = softmax_cross_entropy(lg, targets)
+        r.loss.backward()
+        ref_in = logits.double().requires_grad_()
+        ref = F.cross_entropy(ref_in, targets, ignore_index=-100)
+        ref.backward()
+        assert torch.isfinite(r.loss)
+        torch.testing.assert_close(r.loss.double(), ref.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(lg.grad.double(), ref_in.grad, rtol=1e-4, atol=1e-7)
+        assert r.correct.tolist() == [True, True, True, True, False, False]
+        assert r.metrics[2].item() == 5
+        assert torch.count_nonzero(lg.grad[4]) == 0
+
+
+def test_xent_sum_none_and_inplace_backward():
+    from distributed_pytorch_amd.ops import softmax_cross_entropy
+
+    torch.manual_seed(5)
+    logits = torch.randn(40, 777, device=DEV)
+    t = torch.randint(0, 777, (40,), device=DEV)
+    a = logits.clone().requires_grad_()
+    r = softmax_cross_entropy(a, t, reduction="sum")
+    r.loss.backward()
+    b = logits.clone().double().requires_grad_()
+    F.cross_entropy(b, t, reduction="sum").backward()
+    torch.testing.assert_close(a.grad.double(), b.grad, rtol=1e-4, atol=1e-6)
+    c = logits.clone().requires_grad_()
+    w = torch.rand(40, device=DEV)
+    (softmax_cross_entropy(c, t, reduction="none").loss * w).sum().backward()
+    d = logits.clone().double().requires_grad_()
+    (F.cross_entropy(d, t, reduction="none") * w.double()).sum().backward()
+    torch.testing.assert_close(c.grad.double(), d.grad, rtol=1e-4, atol=1e-6)
+    # in-place: the gradient is written over the logits buffer
+    e = logits.clone()
+    leaf = torch.zeros_like(e, requires_grad=True)
+    y = leaf + e
+    softmax_cross_entropy(y, t, inplace_backward=True).loss.backward()
+    torch.testing.assert_close(leaf.grad.double(), b.grad / 40, rtol=1e-4, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- linear layers
+def _ref_linear(x, w, b, act):
+    y = x.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "gelu":
+        y = F.gelu(y)
+    return y
+
+
+@pytest.mark.parametrize("M,K,N", [(8, 1, 32), (1, 1, 4096), (1000, 1, 4096), (77, 1, 33),      # K = 1 outer product
+                                   (8, 32, 4), (1000, 4096, 4), (65, 100, 3), (9, 4096, 16),    # skinny N
+                                   (256, 256, 256), (130, 68, 260), (1, 64, 128), (512, 1024, 96), (300, 36, 52)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_forward_backward(M, K, N, dtype):
+    from distributed_pytorch_amd.ops.linear import linear_bias_act, native_route
+
+    if dtype == torch.bfloat16 and K != 1 and N > 16 and (K % 8 or N % 8):
+        pytest.skip("bf16 MFMA path needs multiples of 8")
+    torch.manual_seed(M + 7 * K + 13 * N)
+    x = torch.randn(M, K, device=DEV).to(dtype)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, device=DEV).to(dtype)
+    assert native_route(M, N, K, dtype) in ("outer", "skinny", "mfma")
+    xs, ws, bs = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = linear_bias_act(xs, ws, bs, allow_library_gemm=False)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = _ref_linear(xr, wr, br, None)
+    yr.backward(gy.double())
+    t = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y.double(), yr.detach(), **t)
+    scale = math.sqrt(max(M, 1))
+    tg = dict(rtol=3e-2, atol=3e-2 * scale) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4 * scale)
+    torch.testing.assert_close(xs.grad.double(), xr.grad, **t)
+    torch.testing.assert_close(ws.grad.double(), wr.grad, **tg)
+    torch.testing.assert_close(bs.grad.double(), br.grad, **tg)
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(200, 1, 512), (256, 128, 384), (100, 72, 136)])
+def test_linear_fused_activation(act, dtype, M, K, N):
+    from distributed_pytorch_amd.ops.linear import linear_bias_act
+
+    torch.manual_seed(11)
+    x = torch.randn(M, K, device=DEV).to(dtype)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, device=DEV).to(dtype)
+    xs, ws, bs = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = linear_bias_act(xs, ws, bs, act=act, allow_library_gemm=False)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = _ref_linear(xr, wr, br, act)
+    yr.backward(gy.double())
+    t = dict(rtol=3e-2, atol=5e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    tg = dict(rtol=3e-2, atol=0.6) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=2e-3)
+    tx = dict(rtol=3e-2, atol=0.2) if dtype == torch.bfloat16 else t  # dx sums N bf16-rounded terms
+    torch.testing.assert_close(y.double(), yr.detach(), **t)
+    torch.testing.assert_close(xs.grad.double(), xr.grad, **tx)
+    torch.testing.assert_close(ws.grad.double(), wr.grad, **tg)
+    torch.testing.assert_close(bs.grad.double(), br.grad, **tg)
+
+
+@pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_layouts_identity_and_asymmetric(a_k, b_k, dtype):
+    """A = I against an asymmetric B catches swapped row/column maps in the MFMA C layout;
+    exact small-integer data makes every product exact in bf16 and fp32."""
+    M, N, K = 192, 136, 192
+    A = torch.eye(M, K, device=DEV)
+    Bm = (torch.arange(K, device=DEV).view(K, 1) % 7 - 3.0) + 2.0 * (torch.arange(N, device=DEV).view(1, N) % 5)  # B[k][n]
+    Aop = (A if a_k else A.t().contiguous()).to(dtype)
+    Bop = (Bm.t().contiguous() if b_k else Bm.contiguous()).to(dtype)
+    out = C().gemm(Aop, Bop, a_k, b_k)
+    ref = (A.double() @ Bm.double())
+    assert torch.equal(out.double(), ref)
+    # random integers in every operand, all four layouts
+    torch.manual_seed(3)
+    M, N, K = 264, 200, 328
+    Af = torch.randint(-3, 4, (M, K), device=DEV).float()
+    Bf = torch.randint(-3, 4, (K, N), device=DEV).float()
+    Aop = (Af if a_k else Af.t().contiguous()).to(dtype)
+    Bop = (Bf.t().contiguous() if b_k else Bf.contiguous()).to(dtype)
+    out = C().gemm(Aop, Bop, a_k, b_k)
+    ref = Af.double() @ Bf.double()
+    if dtype == torch.bfloat16:
+        torch.testing.assert_close(out.double(), ref, rtol=1e-2, atol=1.0)  # outputs up to ~3000 are rounded to bf16
+    else:
+        assert torch.equal(out.double(), ref)
+
+
+def test_gemm_large_random_f32_and_bf16():
+    torch.manual_seed(9)
+    for dtype, t in ((torch.float32, dict(rtol=1e-4, atol=1e-3)), (torch.bfloat16, dict(rtol=2e-2, atol=0.5))):
+        A = torch.randn(1024, 2048, device=DEV).to(dtype)
+        B = torch.randn(1536, 2048, device=DEV).to(dtype)
+        out = C().gemm(A, B, True, True)
+        ref = A.double() @ B.double().t()
+        torch.testing.assert_close(out.double(), ref, **t)
+
+
+# ----------------------------------------------------------------------------- layer norm
+@pytest.mark.parametrize("rows,cols", [(1, 768), (5, 768), (4097, 768), (33, 64), (16, 1024), (7, 2048)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(rows, cols, dtype):
+    from distributed_pytorch_amd.ops.layernorm import layer_norm
+
+    if dtype == torch.float32 and cols > 1024:
+        pytest.skip("fp32 backward keeps at most 1024 columns in registers")
+    torch.manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, device=DEV) * 2 + 0.5).to(dtype)
+    g = torch.randn(cols, device=DEV).to(dtype)
+    b = torch.randn(cols, device=DEV).to(dtype)
+    xs, gs, bs = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    y = layer_norm(xs, gs, bs, 1e-5)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr, gr, br = x.double().requires_grad_(), g.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    yr.backward(gy.double())
+    t = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    s = math.sqrt(rows)
+    tg = dict(rtol=3e-2, atol=5e-2 * s) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4 * s)
+    torch.testing.assert_close(y.double(), yr.detach(), **t)
+    torch.testing.assert_close(xs.grad.double(), xr.grad, **t)
+    torch.testing.assert_close(gs.grad.double(), gr.grad, **tg)
+    torch.testing.assert_close(bs.grad.double(), br.grad, **tg)

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Training-throughput benchmark: samples/sec of the whole job on N GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--model gpt2|widemlp|resnet50|dummy]
+
+Default workload: GPT-2 small, synthetic 1024-token sequences, bf16 parameters with fp32
+master weights, data parallel over N ranks (one process per GPU, RCCL over xGMI).  For
+N > 1 start it with ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`` (RANK / LOCAL_RANK /
+WORLD_SIZE are read from the environment); started plainly with ``--gpus N`` it spawns the
+ranks itself through ``distributed.launch``.
+
+Every step is a full training step -- forward, loss, backward (with bucketed gradient
+all-reduce when N > 1), optimizer update -- on device-resident synthetic data and
+random-initialised weights.  W warm-up steps are not timed; exactly K steps are timed between
+``barrier + torch.cuda.synchronize()`` on both sides; the slowest rank's time counts.  Rank 0
+prints one JSON line; ``value`` is the aggregate samples/sec over all N GPUs (a sample is one
+sequence / image / row).  Per-GPU work is fixed as N grows (weak scaling).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--model", default="gpt2", choices=["gpt2", "gpt2-medium", "widemlp", "resnet50", "dummy"])
+    p.add_argument("--batch-size", type=int, default=None, help="per-GPU batch (default depends on the model)")
+    p.add_argument("--seq-len", type=int, default=1024)
+    p.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="compute dtype (default bf16; dummy: fp32)")
+    p.add_argument("--linear-impl", default=os.environ.get("BENCH_LINEAR_IMPL", "auto"), choices=["auto", "native", "library", "stock"])
+    p.add_argument("--reduce-dtype", default=None, choices=["fp32", "bf16"], help="gradient all-reduce dtype")
+    p.add_argument("--bucket-mb", type=float, default=None)
+    p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
+    p.add_argument("--stock", action="store_true", help="comparison run: stock torch ops and torch.optim.AdamW(fused=True)")
+    p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph")
+    p.add_argument("--json-out", default=None, help="also write the JSON line to this file")
+    return p.parse_args(argv)
+
+
+# --------------------------------------------------------------------------- workloads
+def build_workload(args, device):
+    """Returns (model, step_inputs_fn, loss_fn, per_gpu_batch, info)."""
+    import torch
+
+    from distributed_pytorch_amd.models import GPT2, DummyModel, GPT2Config, WideMLP, resnet50
+    from distributed_pytorch_amd.ops import SoftmaxCrossEntropy
+
+    name = args.model
+    g = torch.Generator(device="cpu").manual_seed(1234 + int(os.environ.get("RANK", "0")))
+    if name in ("gpt2", "gpt2-medium"):
+        dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+        B = args.batch_size or 32
+        T = args.seq_len
+        cfg = (GPT2Config.small if name == "gpt2" else GPT2Config.medium)(
+            block_size=max(T, 1024), linear_impl="stock" if args.stock else args.linear_impl, native_ops=not args.stock)
+        model = GPT2(cfg).to(device=device, dtype=dtype)
+        idx = torch.randint(0, cfg.vocab_size, (B, T), generator=g).to(device)
+        tgt = torch.randint(0, cfg.vocab_size, (B, T), generator=g).to(device)
+        loss_fn = lambda m: m(idx, tgt)
+        info = dict(model="gpt2-small" if name == "gpt2" else "gpt2-medium", seq_len=T, params=model.num_parameters(),
+                    flops_per_sample=model.flops_per_token(T) * T, tokens_per_sample=T)
+        return model, loss_fn, B, dtype, info
+    if name == "widemlp":
+        dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+        B = args.batch_size or 8192
+        model = WideMLP(8192, 8192, 8, 1024).to(device=device, dtype=dtype)
+        x = torch.randn(B, 8192, generator=g).to(device=device, dtype=dtype)
+        y = torch.randint(0, 1024, (B,), generator=g).to(device)
+        crit = SoftmaxCrossEntropy()
+        loss_fn = lambda m: crit(m(x), y)
+        info = dict(model="wide-mlp-8x8192", seq_len=None, params=sum(p.numel() for p in model.parameters()),
+                    flops_per_sample=model.flops_per_sample(), tokens_per_sample=1)
+        return model, loss_fn, B, dtype, info
+    if name == "resnet50":
+        dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+        B = args.batch_size or 256
+        model = resnet50().to(device=device, dtype=dtype).to(memory_format=torch.channels_last)
+        x = torch.randn(B, 3, 224, 224, generator=g).to(device=device, dtype=dtype).contiguous(memory_format=torch.channels_last)
+        y = torch.randint(0, 1000, (B,), generator=g).to(device)
+        crit = SoftmaxCrossEntropy()
+        loss_fn = lambda m: crit(m(x), y)
+        info = dict(model="resnet50", seq_len=None, params=sum(p.numel() for p in model.parameters()),
+                    flops_per_sample=3 * 4.09e9 * 2, tokens_per_sample=1)
+        return model, loss_fn, B, dtype, info
+    # dummy: the reference model at hidden_dim 4096 on the native K=1 / N=4 kernels
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B = args.batch_size or 65536
+    model = DummyModel(1, 4096, 4, native=True).to(device=device, dtype=dtype)
+    x = (torch.arange(B, dtype=torch.float32).unsqueeze(1) / B).to(device=device, dtype=dtype)
+    y = torch.randint(0, 4, (B,), generator=g).to(device)
+    crit = SoftmaxCrossEntropy()
+    loss_fn = lambda m: crit(m(x), y)
+    info = dict(model="min_DDP-DummyModel-hidden4096", seq_len=None, params=sum(p.numel() for p in model.parameters()),
+                flops_per_sample=6.0 * (4096 + 4 * 4096), tokens_per_sample=1)
+    return model, loss_fn, B, dtype, info
+
+
+# --------------------------------------------------------------------------- one rank
+def run_rank(rank: int, world_size: int, argv):
+    args = parse_args(argv)
+    import torch
+
+    import distributed as dist
+    from distributed_pytorch_amd import _ext
+    from distributed_pytorch_amd.ops import FusedAdamW
+    from distributed_pytorch_amd.parallel import process_group as pg
+
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        _ext.C()  # the HIP extension is mandatory on a GPU box
+    if world_size > 1:
+        dist.init_process_group(rank, world_size, args.backend)
+    device = dist.get_device()
+    if use_gpu:
+        torch.cuda.set_device(device)
+    torch.manual_seed(0)
+
+    model, loss_fn, per_gpu_batch, dtype, info = build_workload(args, device)
+    ddp_kwargs = {}
+    if args.reduce_dtype:
+        ddp_kwargs["reduce_dtype"] = args.reduce_dtype
+    if args.bucket_mb:
+        ddp_kwargs["bucket_cap_mb"] = args.bucket_mb
+    model = dist.prepare_ddp_model(model, device_ids=[device.index if device.type == "cuda" else None], **ddp_kwargs)
+    if args.stock:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, fused=use_gpu)
+    else:
+        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, master_weights=(dtype != torch.float32))
+
+    def train_step():
+        loss = loss_fn(model)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync():
+        dist.barrier()
+        if use_gpu:
+            torch.cuda.synchronize(device)
+
+    step = train_step
+    graph = None
+    if args.graph and use_gpu and world_size == 1:
+        from distributed_pytorch_amd.utils.graph import GraphedStep
+
+        graph = GraphedStep(model, opt, loss_fn)
+        step = graph.step
+
+    first_loss = None
+    for i in range(args.warmup):
+        l = step()
+        if i == 0:
+            first_loss = l
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if (world_size > 1 and pg.get_backend() == "rccl") else "cpu")
+    if world_size > 1:
+        pg.all_reduce(t, "max")
+    elapsed = float(t.item())
+    final_loss = float(last.detach().float().item()) if last is not None else float("nan")
+
+    n = max(world_size, 1)
+    ms = elapsed / args.steps * 1e3
+    samples_per_sec = per_gpu_batch * n * args.steps / elapsed
+    result = {
+        "metric": "samples_per_sec",
+        "value": round(samples_per_sec, 3),
+        "unit": "samples/s",
+        "n_gpus": n if use_gpu else 0,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16" if dtype == torch.bfloat16 else "fp32",
+        "data": "synthetic",
+        "config": {
+            "model": info["model"],
+            "global_batch": per_gpu_batch * n,
+            "per_gpu_batch": per_gpu_batch,
+            "seq_len": info["seq_len"],
+            "parallelism": f"dp{n}",
+            "params": info["params"],
+            "optimizer": "torch.optim.AdamW(fused)" if args.stock else "FusedAdamW" + ("+fp32-master" if dtype != torch.float32 else ""),
+            "stock_torch_ops": bool(args.stock),
+            "linear_impl": args.linear_impl,
+            "grad_reduce_dtype": (args.reduce_dtype or ("param dtype" if n > 1 else None)),
+            "comm": (pg.get_backend() if n > 1 else None),
+            "hip_graph": bool(graph is not None),
+        },
+        "tokens_per_sec": round(samples_per_sec * info["tokens_per_sample"], 1),
+        "model_tflops_per_gpu": round(info["flops_per_sample"] * per_gpu_batch / (ms * 1e-3) / 1e12, 2),
+        "final_loss": round(final_loss, 5),
+        "first_loss": round(float(first_loss.detach().float().item()), 5) if first_loss is not None else None,
+    }
+    if use_gpu:
+        result["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
+    if dist.is_primary():
+        line = json.dumps(result)
+        print(line, flush=True)
+        if args.json_out:
+            Path(args.json_out).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.json_out).write_text(line + "\n")
+    dist.cleanup()
+
+
+def _spawned_worker(rank, world_size, argv):
+    run_rank(rank, world_size, argv)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world not in (None, ""):  # started by torchrun (or any launcher exporting the rendezvous env)
+        run_rank(int(os.environ.get("RANK", "0")), int(env_world), argv)
+        return
+    if args.gpus <= 1:
+        run_rank(0, 1, argv)
+        return
+    # plain `python bench.py --gpus N`: spawn the ranks ourselves
+    import distributed as dist
+
+    if not any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")):
+        os.environ["HIP_VISIBLE_DEVICES"] = ",".join(str(i) for i in range(args.gpus))
+    dist.launch(_spawned_worker, argv, nprocs=args.gpus)
+
+
+if __name__ == "__main__":
+    main()

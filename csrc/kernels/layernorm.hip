@@ -159,15 +159,26 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
   }
 }
 
+// dgamma / dbeta = column sums of the per-workgroup partial rows.  32 outputs per workgroup,
+// 8 row groups x 32 columns of threads, LDS combine (see reduce_partials_kernel in skinny.hip).
 template <typename TR>
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, typename TR::T* __restrict__ dgamma,
                                                                         typename TR::T* __restrict__ dbeta, int cols, int nblocks) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= 2 * cols) return;
+  __shared__ float red[8][33];
+  const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cc;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[static_cast<size_t>(b) * 2 * cols + c];
-  if (c < cols) dgamma[c] = TR::from_f32(s);
-  else dbeta[c - cols] = TR::from_f32(s);
+  if (c < 2 * cols)
+    for (int b = rg; b < nblocks; b += 8) s += partial[static_cast<size_t>(b) * 2 * cols + c];
+  red[rg][cc] = s;
+  __syncthreads();
+  if (rg == 0 && c < 2 * cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cc];
+    if (c < cols) dgamma[c] = TR::from_f32(t);
+    else dbeta[c - cols] = TR::from_f32(t);
+  }
 }
 
 int pick_blocks(long long rows) {
@@ -224,7 +235,7 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, cons
                          static_cast<const T*>(dy), static_cast<const T*>(x), static_cast<const T*>(gamma), mean, rstd, static_cast<T*>(dx),
                          workspace, rows, static_cast<int>(cols));
     });
-    hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((2 * cols + kThreads - 1) / kThreads)), dim3(kThreads),
+    hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((2 * cols + 31) / 32)), dim3(kThreads),
                        0, stream, workspace, static_cast<T*>(dgamma), static_cast<T*>(dbeta), static_cast<int>(cols), blocks);
   });
 }

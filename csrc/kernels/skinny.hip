@@ -226,16 +226,27 @@ __global__ __launch_bounds__(kThreads) void skinny_n_wgrad_partial_kernel(const 
       for (int j = 0; j < V && k0 + j < K; ++j) out[n * K + k0 + j] = acc[n][j];
 }
 
-// out[i] = sum_c partial[c][i], i in [0, len)
+// out[i] = sum_c partial[c][i], i in [0, len).  A workgroup owns 32 consecutive outputs; its
+// 256 threads form 8 row groups x 32 columns, so every load instruction reads 128 contiguous
+// bytes per row and a thread walks only chunks/8 rows; LDS combines the 8 row groups.
 template <typename TR>
 __global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* __restrict__ partial,
                                                                    typename TR::T* __restrict__ out, long long len,
                                                                    int chunks) {
-  const long long i = static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x;
-  if (i >= len) return;
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const long long i = static_cast<long long>(blockIdx.x) * 32 + c;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += partial[static_cast<long long>(c) * len + i];
-  out[i] = TR::from_f32(s);
+  if (i < len)
+    for (int r = rg; r < chunks; r += 8) s += partial[static_cast<long long>(r) * len + i];
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && i < len) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    out[i] = TR::from_f32(t);
+  }
 }
 
 // ------------------------------------------------------------------ column reductions over [M, N]
@@ -349,7 +360,7 @@ void col_reduce(const void* dy, const void* aux, void* g, void* db, void* dw, fl
   } else
   hipLaunchKernelGGL((col_reduce_partial_kernel<TR, MODE>), dim3(col_tiles, chunks), dim3(kThreads), 0, stream,
                      static_cast<const T*>(dy), static_cast<const T*>(aux), static_cast<T*>(g), pb, pw, M, N, rpc, act);
-  const int rb = static_cast<int>((N + kThreads - 1) / kThreads);
+  const int rb = static_cast<int>((N + 31) / 32);
   if (db)
     hipLaunchKernelGGL((reduce_partials_kernel<TR>), dim3(rb), dim3(kThreads), 0, stream, pb, static_cast<T*>(db), N, chunks);
   if (MODE == kOuterWgrad && dw)
@@ -435,7 +446,7 @@ void launch_skinny_n_wgrad(const void* dy, const void* x, void* dW, void* db, fl
     else if (N <= 8) go(std::integral_constant<int, 8>{});
     else go(std::integral_constant<int, 16>{});
     const long long len = N * K;
-    hipLaunchKernelGGL((reduce_partials_kernel<TR>), dim3(static_cast<unsigned>((len + kThreads - 1) / kThreads)),
+    hipLaunchKernelGGL((reduce_partials_kernel<TR>), dim3(static_cast<unsigned>((len + 31) / 32)),
                        dim3(kThreads), 0, stream, workspace, static_cast<T*>(dW), len, chunks);
     if (db) col_reduce<TR, kColSum>(dy, nullptr, nullptr, db, nullptr, workspace + static_cast<long long>(chunks) * len, M, N, 0, stream);
   });

@@ -377,6 +377,18 @@ std::tuple<Tensor, c10::optional<Tensor>> act_backward(Tensor dy, Tensor saved, 
   return {gout, db};
 }
 
+// db[N] = column sums of dy[M,N] (bias gradient), fp32 accumulation, deterministic.
+Tensor colsum(Tensor dy) {
+  check_gpu(dy, "dy");
+  TORCH_CHECK(dy.dim() == 2, "colsum: [M, N] expected");
+  const int64_t M = dy.size(0), N = dy.size(1);
+  Tensor db = at::empty({N}, dy.options());
+  Tensor ws = at::empty({kernels::colreduce_workspace(M, N)}, dy.options().dtype(at::kFloat));
+  DevGuard guard(dy);
+  kernels::launch_colsum(dy.data_ptr(), db.data_ptr(), ws.data_ptr<float>(), M, N, kdtype(dy), stream_of(dy));
+  return db;
+}
+
 // General matrix product on the MFMA kernels (used by tests and benchmarks):
 // C[M,N] = alpha * op(A) op(B)^T with the layout flags of kernels::GemmArgs.
 Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tensor> bias, int64_t act) {
@@ -470,6 +482,7 @@ void init_ops(py::module_& m) {
   m.def("linear_forward", &linear_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("act") = 0, py::arg("save_pre_act") = false);
   m.def("linear_backward", &linear_backward, py::arg("grad"), py::arg("x"), py::arg("weight"), py::arg("need_dx") = true, py::arg("need_db") = true);
   m.def("act_backward", &act_backward, py::arg("dy"), py::arg("saved"), py::arg("act"), py::arg("need_db") = false);
+  m.def("colsum", &colsum);
   m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),
         py::arg("act") = 0);
   m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5);

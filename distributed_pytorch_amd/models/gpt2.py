@@ -8,9 +8,11 @@ native kernels: layer norm, the MLP up-projection with fused bias + GELU epilogu
 every logits row is 16-byte aligned, gradient written in place over the logits), and the
 optimizer (FusedAdamW).  Attention uses torch's fused scaled-dot-product kernel.
 
-``linear_impl``: ``"native"`` routes every projection through the hand-written MFMA GEMM,
-``"library"`` through the vendor GEMM behind ``F.linear`` (plain GEMMs without a fused
-epilogue), ``"auto"`` keeps the native kernel only where it fuses an epilogue.
+``linear_impl``: ``"native"`` routes every projection through the hand-written MFMA GEMM;
+``"library"`` runs the plain GEMMs on the vendor library and everything around them
+(activation backward, bias gradients) on our kernels; ``"auto"`` uses the native GEMM where
+it fuses an epilogue (the GELU up-projection) and the library elsewhere; ``"stock"`` is
+unmodified torch (``F.linear`` / ``F.gelu``), the comparison baseline.
 """
 from __future__ import annotations
 
@@ -24,7 +26,7 @@ import torch.nn.functional as F
 
 from ..ops.cross_entropy import softmax_cross_entropy
 from ..ops.layernorm import LayerNorm
-from ..ops.linear import linear_bias_act
+from ..ops.linear import library_linear_bias_act, linear_bias_act
 
 
 @dataclass
@@ -38,6 +40,7 @@ class GPT2Config:
     vocab_pad_multiple: int = 64
     linear_impl: str = "auto"     # native | library | auto
     inplace_loss_backward: bool = True
+    native_ops: bool = True       # False: stock torch layer norm / GELU / cross-entropy (comparison baseline)
 
     @property
     def padded_vocab_size(self) -> int:
@@ -65,6 +68,8 @@ class _Proj(nn.Linear):
         use_native = self.impl == "native" or (self.impl == "auto" and self.act is not None)
         if use_native and x.is_cuda:
             return linear_bias_act(x, self.weight, self.bias, self.act)
+        if self.impl in ("library", "auto") and x.is_cuda:
+            return library_linear_bias_act(x, self.weight, self.bias, self.act)
         y = F.linear(x, self.weight, self.bias)
         if self.act == "gelu":
             y = F.gelu(y)
@@ -106,9 +111,10 @@ class MLP(nn.Module):
 class Block(nn.Module):
     def __init__(self, cfg: GPT2Config):
         super().__init__()
-        self.ln_1 = LayerNorm(cfg.n_embd)
+        LN = LayerNorm if cfg.native_ops else nn.LayerNorm
+        self.ln_1 = LN(cfg.n_embd)
         self.attn = CausalSelfAttention(cfg)
-        self.ln_2 = LayerNorm(cfg.n_embd)
+        self.ln_2 = LN(cfg.n_embd)
         self.mlp = MLP(cfg)
 
     def forward(self, x):
@@ -125,7 +131,7 @@ class GPT2(nn.Module):
         self.wte = nn.Embedding(V, cfg.n_embd)
         self.wpe = nn.Embedding(cfg.block_size, cfg.n_embd)
         self.h = nn.ModuleList([Block(cfg) for _ in range(cfg.n_layer)])
-        self.ln_f = LayerNorm(cfg.n_embd)
+        self.ln_f = (LayerNorm if cfg.native_ops else nn.LayerNorm)(cfg.n_embd)
         # lm_head shares the token-embedding matrix (weight tying), so it has no parameter of its own
         self.apply(self._init_weights)
         for name, p in self.named_parameters():
@@ -163,6 +169,9 @@ class GPT2(nn.Module):
         if targets is None:
             return F.linear(x[:, -1:, :], self.wte.weight)[..., : self.cfg.vocab_size]
         logits = F.linear(x, self.wte.weight)  # [B, T, padded vocab]: plain GEMM, vendor library
+        if not self.cfg.native_ops:
+            lg = logits.view(B * T, -1)[:, : self.cfg.vocab_size]
+            return F.cross_entropy(lg.float(), targets.reshape(-1))
         r = softmax_cross_entropy(logits.view(B * T, -1), targets.reshape(-1), n_classes=self.cfg.vocab_size,
                                   inplace_backward=self.cfg.inplace_loss_backward)
         self.last_correct, self.last_metrics = r.correct, r.metrics

@@ -87,6 +87,48 @@ class _LinearBiasAct(torch.autograd.Function):
         return dx, dw, (db if ctx.has_bias else None), None
 
 
+class _LibraryGemmLinear(torch.autograd.Function):
+    """Plain GEMMs on the vendor library (hipBLASLt behind torch.mm / addmm), everything around
+    them on our kernels: activation backward fused with the bias gradient in one pass over dy,
+    bias gradient as a deterministic two-stage column sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: int):
+        pre = F.linear(x, weight, bias)
+        y = _torch_act(pre, act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, pre if act == ACT_GELU else (y if act == ACT_RELU else None))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = _ext.C()
+        x, weight, saved = ctx.saved_tensors
+        dy = dy.contiguous()
+        db = None
+        if ctx.act != ACT_NONE:
+            g, db = C.act_backward(dy, saved, ctx.act, ctx.has_bias)
+        else:
+            g = dy
+            if ctx.has_bias:
+                db = C.colsum(dy)
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = g.t() @ x
+        return dx, dw, db, None
+
+
+def library_linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None) -> torch.Tensor:
+    """``act(x @ weight.T + bias)`` with vendor-library GEMMs and native elementwise/reduction kernels."""
+    code = _act_code(act)
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return _torch_act(F.linear(x, weight, bias), code)
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    y = _LibraryGemmLinear.apply(x2, weight, bias, code)
+    return y.reshape(*lead, weight.shape[0])
+
+
 def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
                     allow_library_gemm: bool = True) -> torch.Tensor:
     """``act(x @ weight.T + bias)`` for x of shape ``[..., K]``.

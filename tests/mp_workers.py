@@ -1,0 +1,160 @@
+"""Worker functions for the multi-process CPU tests (importable by spawned children).
+Each worker writes what it observed to ``<out_dir>/rank<r>.json``; the parent asserts."""
+import json
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+
+def _dump(out_dir, rank, obj):
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(obj, f)
+
+
+def collectives_worker(rank, world_size, out_dir):
+    import distributed as dist
+
+    dist.init_process_group(rank, world_size, "gloo")
+    res = {"rank": dist.get_rank(), "world": dist.get_world_size(), "primary": dist.is_primary(),
+           "initialised": dist.is_dist_avail_and_initialized(), "device": str(dist.get_device())}
+    t = torch.tensor([1.0 + rank, 10.0 * (rank + 1)])
+    r = dist.reduce(t)
+    res["reduce_same_object"] = r is t
+    res["reduce"] = t.tolist()
+    a = torch.tensor([float(rank + 1)])
+    res["all_reduce_sum"] = dist.all_reduce(a.clone()).tolist()
+    res["all_reduce_avg"] = dist.all_reduce(a.clone(), "avg").tolist()
+    try:
+        dist.all_reduce(a.clone(), "max")
+        res["bad_op"] = None
+    except ValueError as e:
+        res["bad_op"] = str(e)
+    g = dist.gather(torch.tensor([rank, rank * 2]))
+    res["gather"] = [x.tolist() for x in g]
+    gb = dist.gather(torch.tensor([rank % 2 == 0, True]))
+    res["gather_bool"] = [x.tolist() for x in gb]
+    res["gather_bool_dtype"] = str(gb[0].dtype)
+    p = torch.full((3,), float(rank))
+    dist.sync_params([p])
+    res["sync_params"] = p.tolist()
+    red = dist.reduce(torch.tensor([2.0 + rank]), op=torch.distributed.ReduceOp.MAX)
+    res["reduce_max"] = red.tolist()
+    dist.barrier()
+    dist.wait_for_everyone()
+    s = dist.data_sampler(list(range(10)), True, shuffle=False)
+    res["sampler"] = list(s)
+    _dump(out_dir, rank, res)
+    dist.cleanup()
+    assert not dist.is_dist_avail_and_initialized()
+
+
+class _Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 16)
+        self.b = nn.Linear(16, 16)
+        self.c = nn.Linear(16, 3)
+        self.bn = nn.BatchNorm1d(16)
+        self.unused = nn.Linear(4, 4)  # never takes part in forward
+
+    def forward(self, x):
+        return self.c(torch.relu(self.bn(self.b(torch.relu(self.a(x))))))
+
+
+def ddp_vs_torch_worker(rank, world_size, out_dir):
+    """Same seed, same data: our wrapper and torch's DDP must end with the same parameters."""
+    import torch.distributed as tdist
+    from torch.nn.parallel import DistributedDataParallel as TorchDDP
+
+    import distributed as dist
+    from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+    dist.init_process_group(rank, world_size, "gloo")
+    torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's
+    ours_m = _Net()
+    torch.manual_seed(100 + rank)
+    ref_m = _Net()
+    ours = DistributedDataParallel(ours_m, device_ids=[rank], bucket_cap_mb=0.0005, first_bucket_mb=0.0002)
+    ref = TorchDDP(ref_m, find_unused_parameters=True)
+    res = {"n_buckets": ours.reducer.num_buckets(), "keys": list(ours.state_dict().keys())[:3]}
+    o1 = torch.optim.SGD(ours.parameters(), 0.1)
+    o2 = torch.optim.SGD(ref.parameters(), 0.1)
+    g = torch.Generator().manual_seed(7 + rank)
+    for step in range(4):
+        x = torch.randn(8, 6, generator=g)
+        y = torch.randint(0, 3, (8,), generator=g)
+        for m, o in ((ours, o1), (ref, o2)):
+            o.zero_grad()
+            nn.functional.cross_entropy(m(x), y).backward()
+            o.step()
+    diffs = [float((a - b).abs().max()) for (na, a), (nb, b) in zip(ours.module.named_parameters(), ref.module.named_parameters())
+             if not na.startswith("unused")]
+    res["max_param_diff"] = max(diffs)
+    res["bn_running_mean_diff"] = float((ours.module.bn.running_mean - ref.module.bn.running_mean).abs().max())
+    res["checksum"] = float(ours.parameter_checksum())
+    res["in_sync"] = ours.check_replicas_in_sync()
+    # torch-DDP checkpoints load into ours and vice versa (same "module." layout)
+    ours.load_state_dict(ref.state_dict())
+    ref.load_state_dict(ours.state_dict())
+    # no_sync accumulates locally, the next synced backward reduces the sum
+    ours.zero_grad(set_to_none=True)
+    x = torch.full((4, 6), float(rank + 1))
+    with ours.no_sync():
+        ours(x).sum().backward()
+    g_local = ours.module.c.bias.grad.clone()
+    ours(x).sum().backward()
+    res["no_sync_local_grad"] = g_local.tolist()
+    res["no_sync_final_grad"] = ours.module.c.bias.grad.tolist()
+    res["syncs"] = ours.reducer.num_backward_syncs()
+    res["unused_grad_is_zero"] = bool(ours.module.unused.weight.grad is None or float(ours.module.unused.weight.grad.abs().sum()) == 0.0)
+    _dump(out_dir, rank, res)
+    dist.cleanup()
+
+
+def crash_worker(rank, world_size, out_dir):
+    import distributed as dist
+
+    dist.init_process_group(rank, world_size, "gloo")
+    with open(os.path.join(out_dir, f"pid{rank}"), "w") as f:
+        f.write(str(os.getpid()))
+    if rank == 1:
+        raise RuntimeError("boom from rank 1")
+    time.sleep(60)  # the survivors would hang here without the launcher's teardown
+
+
+def exit_code_worker(rank, world_size, out_dir):
+    if rank == 0:
+        os._exit(7)
+    time.sleep(60)
+
+
+def extra_args_worker(rank, world_size, out_dir, a, b):
+    _dump(out_dir, rank, {"rank": rank, "world": world_size, "a": a, "b": b,
+                          "env_rank": os.environ.get("RANK"), "env_world": os.environ.get("WORLD_SIZE"),
+                          "master_port": os.environ.get("MASTER_PORT"), "hosted": os.environ.get("DIST_STORE_HOSTED"),
+                          "affinity": sorted(os.sched_getaffinity(0))})
+
+
+def checkpoint_worker(rank, world_size, out_dir):
+    import distributed as dist
+    from distributed_pytorch_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+
+    dist.init_process_group(rank, world_size, "gloo")
+    torch.manual_seed(0)
+    model = dist.prepare_ddp_model(nn.Linear(4, 2), device_ids=[rank])
+    opt = torch.optim.AdamW(model.parameters(), 1e-2)
+    model(torch.ones(3, 4)).sum().backward()
+    opt.step()
+    path = os.path.join(out_dir, "ckpt.pt")
+    save_checkpoint(path, model, opt, step=5, extra={"note": "hi"})
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+    meta = load_checkpoint(path, model, opt)
+    same = all(torch.equal(before[k], v) for k, v in model.state_dict().items())
+    _dump(out_dir, rank, {"restored": same, "step": meta["step"], "note": meta["extra"]["note"],
+                          "keys": list(before.keys())})
+    dist.cleanup()

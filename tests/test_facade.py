@@ -1,0 +1,136 @@
+"""The drop-in API contract of the top-level ``distributed`` module without any process
+group: every query / collective degrades to the single-process answer, exactly as the
+reference helper does (reference distributed.py:69-101, 119-187)."""
+import inspect
+import io
+import socket
+from contextlib import redirect_stdout
+
+import pytest
+import torch
+import torch.nn as nn
+
+import distributed as dist
+
+API = ["find_free_port", "launch", "init_process_group", "is_dist_avail_and_initialized", "cleanup", "get_rank",
+       "get_device", "is_primary", "get_world_size", "data_sampler", "prepare_ddp_model", "all_reduce", "reduce",
+       "gather", "sync_params", "barrier", "wait_for_everyone", "print_primary"]
+
+
+def test_all_eighteen_functions_exist_with_reference_signatures():
+    for name in API:
+        assert callable(getattr(dist, name)), name
+    assert list(inspect.signature(dist.init_process_group).parameters) == ["rank", "world_size", "backend"]
+    assert list(inspect.signature(dist.data_sampler).parameters) == ["dataset", "distributed", "shuffle"]
+    assert list(inspect.signature(dist.prepare_ddp_model).parameters)[:2] == ["model", "device_ids"]
+    assert inspect.signature(dist.all_reduce).parameters["op"].default == "sum"
+    assert inspect.signature(dist.reduce).parameters["op"].default == torch.distributed.ReduceOp.SUM
+    assert list(inspect.signature(dist.launch).parameters)[:2] == ["worker_fn", "args"]
+
+
+def test_single_process_fallbacks():
+    assert not dist.is_dist_avail_and_initialized()
+    assert dist.get_rank() == 0
+    assert dist.get_world_size() == 1
+    assert dist.is_primary()
+    t = torch.arange(4.0)
+    assert dist.all_reduce(t) is t
+    assert dist.all_reduce(t, "avg") is t
+    assert dist.all_reduce(t, "no-such-op") is t  # the op is not even looked at in a single process
+    assert dist.reduce(t) is t
+    g = dist.gather(t)
+    assert isinstance(g, list) and len(g) == 1 and g[0] is t
+    assert dist.barrier() is None and dist.wait_for_everyone() is None
+    assert dist.sync_params([t]) is None
+    assert dist.cleanup() is None  # safe without a group
+    assert torch.equal(t, torch.arange(4.0))
+
+
+def test_get_device_type():
+    d = dist.get_device()
+    assert isinstance(d, torch.device)
+    assert d.type == ("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def test_data_sampler_and_prepare_ddp_model_without_group():
+    ds = list(range(10))
+    assert dist.data_sampler(ds, False, True) is None
+    s = dist.data_sampler(ds, True, False)  # world 1: every index, in order
+    assert list(s) == list(range(10)) and len(s) == 10
+    m = nn.Linear(2, 2)
+    assert dist.prepare_ddp_model(m, device_ids=[0]) is m  # unwrapped: state_dict keys keep no prefix
+    assert list(m.state_dict()) == ["weight", "bias"]
+
+
+def test_print_primary_has_print_signature():
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        dist.print_primary("a", 1, sep="-", end="!\n")
+    assert buf.getvalue() == "a-1!\n"
+
+
+def test_find_free_port_is_bindable():
+    p = dist.find_free_port()
+    assert 1024 < p < 65536
+    with socket.socket() as s:
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.bind(("127.0.0.1", p))
+
+
+# --------------------------------------------------------------------------- launch branch selection
+def test_launch_runs_in_process_for_zero_and_one_device(monkeypatch):
+    calls = []
+    monkeypatch.delenv("DIST_WORLD_SIZE", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    dist.launch(lambda rank, world, *a: calls.append((rank, world, a)), "x", 3)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    dist.launch(lambda rank, world, *a: calls.append((rank, world, a)))
+    # CPU passes world_size 0, one GPU passes 1 (reference distributed.py:54-58)
+    assert calls == [(0, 0, ("x", 3)), (0, 1, ())]
+
+
+def test_launch_refuses_unpinned_multi_gpu(monkeypatch):
+    monkeypatch.delenv("DIST_WORLD_SIZE", raising=False)
+    for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    with pytest.raises(ValueError, match="GPUs not specified"):
+        dist.launch(lambda *a: None)
+
+
+def test_child_device_env_binding_modes(monkeypatch):
+    from distributed_pytorch_amd.parallel.launcher import child_device_env, visible_device_ids
+
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    ids = ["2", "3", "5", "7"]
+    e = child_device_env(ids, 2, "rotate")
+    assert e["HIP_VISIBLE_DEVICES"] == "5,7,2,3" and e["DIST_LOCAL_DEVICE"] == "0" and e["CUDA_VISIBLE_DEVICES"] is None
+    assert child_device_env(ids, 1, "exclusive")["HIP_VISIBLE_DEVICES"] == "3"
+    assert child_device_env(ids, 3, "index") == {"DIST_LOCAL_DEVICE": "3"}
+    with pytest.raises(ValueError):
+        child_device_env(ids, 0, "bogus")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,6")
+    assert visible_device_ids(2) == ["4", "6"]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "1,0")
+    assert visible_device_ids(2) == ["1", "0"]
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
+    assert visible_device_ids(2) is None
+
+
+def test_launcher_never_disables_p2p():
+    import distributed_pytorch_amd.parallel.launcher as L
+
+    src = inspect.getsource(L.launch) + inspect.getsource(L.spawn)
+    assert 'os.environ["NCCL_P2P_DISABLE"]' not in src and "NCCL_P2P_DISABLE=" not in src
+
+
+def test_cpu_slices_partition_affinity():
+    import os
+
+    from distributed_pytorch_amd.parallel.launcher import cpu_slices
+
+    cpus = sorted(os.sched_getaffinity(0))
+    sl = cpu_slices(2)
+    assert len(sl) == 2 and not set(sl[0]) & set(sl[1])
+    assert set(sl[0]) | set(sl[1]) <= set(cpus)

@@ -40,7 +40,7 @@ def parse_args(argv=None):
     p.add_argument("--batch-size", type=int, default=None, help="per-GPU batch (default depends on the model)")
     p.add_argument("--seq-len", type=int, default=1024)
     p.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="compute dtype (default bf16; dummy: fp32)")
-    p.add_argument("--linear-impl", default=os.environ.get("BENCH_LINEAR_IMPL", "auto"), choices=["auto", "native", "library", "stock"])
+    p.add_argument("--linear-impl", default=os.environ.get("BENCH_LINEAR_IMPL", "library"), choices=["auto", "native", "library", "stock"])
     p.add_argument("--reduce-dtype", default=None, choices=["fp32", "bf16"], help="gradient all-reduce dtype")
     p.add_argument("--bucket-mb", type=float, default=None)
     p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
@@ -62,7 +62,7 @@ def build_workload(args, device):
     g = torch.Generator(device="cpu").manual_seed(1234 + int(os.environ.get("RANK", "0")))
     if name in ("gpt2", "gpt2-medium"):
         dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
-        B = args.batch_size or 32
+        B = args.batch_size or 64
         T = args.seq_len
         cfg = (GPT2Config.small if name == "gpt2" else GPT2Config.medium)(
             block_size=max(T, 1024), linear_impl="stock" if args.stock else args.linear_impl, native_ops=not args.stock)

@@ -81,7 +81,7 @@ def build_host(force=False, verbose=False):
             jobs.append(["g++", "-O2", "-g0", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-I" + str(CSRC), *_python_includes(), "-c", s, "-o", o])
     with cf.ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
-    if jobs or not out.exists():
+    if jobs or not out.exists() or any(o.stat().st_mtime > out.stat().st_mtime for o in objs):
         _run(["g++", "-shared", "-o", out, *objs, "-lpthread"], verbose)
     return out
 
@@ -144,7 +144,8 @@ def build_gpu(force=False, verbose=False, jobs_n=8):
     t0 = time.time()
     with cf.ThreadPoolExecutor(max_workers=max(1, jobs_n)) as ex:
         list(ex.map(lambda c: _run(c, verbose), cmds))
-    if cmds or not out.exists():
+    stale = (not out.exists()) or any(o.stat().st_mtime > out.stat().st_mtime for o in objs)
+    if cmds or stale:
         tlib = tdir / "lib"
         _run([
             hipcc, "-shared", f"--offload-arch={GPU_ARCH}", "-fno-gpu-rdc", "-o", out, *objs,

@@ -43,6 +43,51 @@ __device__ __forceinline__ float act_fn(float v, int act) {
   return v;
 }
 
+// Epilogue for one 16x16 accumulator tile computed with SWAPPED MFMA operands (weight fragment
+// first): register e of lane l then holds C[row = m_base + (l&15)][col = n_base + 4*(l>>4) + e],
+// i.e. four consecutive output columns, which leave the lane as ONE 8-byte store instead of four
+// scattered 2-byte stores.
+__device__ __forceinline__ void store_tile_bf16(const GemmArgs& p, const f32x4& acc, long long row, long long col0) {
+  if (row >= p.M || col0 >= p.N) return;
+  u16* C = static_cast<u16*>(p.C);
+  u16* P = static_cast<u16*>(p.pre_act);
+  const u16* bias = static_cast<const u16*>(p.bias);
+  const bool full = (col0 + 4 <= p.N) && ((p.ldc & 3) == 0);
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[e];
+  if (full) {
+    if (bias) {
+      const u16x4 b = *reinterpret_cast<const u16x4*>(bias + col0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += BF16::to_f32(b[e]);
+    }
+    u16* cp = C + row * p.ldc + col0;
+    if (p.beta != 0.f) {
+      const u16x4 old = *reinterpret_cast<const u16x4*>(cp);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += p.beta * BF16::to_f32(old[e]);
+    }
+    if (P) {
+      u16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(v[e]);
+      *reinterpret_cast<u16x4*>(P + row * p.ldc + col0) = o;
+    }
+    u16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(act_fn(v[e], p.act));
+    *reinterpret_cast<u16x4*>(cp) = o;
+  } else {
+    for (int e = 0; e < 4 && col0 + e < p.N; ++e) {
+      float x = v[e] + (bias ? BF16::to_f32(bias[col0 + e]) : 0.f);
+      if (p.beta != 0.f) x += p.beta * BF16::to_f32(C[row * p.ldc + col0 + e]);
+      if (P) P[row * p.ldc + col0 + e] = BF16::from_f32(x);
+      C[row * p.ldc + col0 + e] = BF16::from_f32(act_fn(x, p.act));
+    }
+  }
+}
+
 // Byte offset of 16-byte chunk c (8 k-values) of `row` in the swizzled [128][64] image.
 __device__ __forceinline__ int kmajor_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 // Byte offset of 16-byte chunk c (8 rows) of contraction index k in the swizzled [64][128] image.
@@ -145,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
     if (more) {
       char* an = smem_bf16 + (cur ^ 1) * 2 * kTileBytes;
@@ -156,29 +201,152 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
     cur ^= 1;
   }
 
-  // Epilogue.  Register e of lane l holds C[row = 4*(l>>4) + e][col = l&15] of its 16x16 tile.
-  u16* C = static_cast<u16*>(p.C);
-  u16* P = static_cast<u16*>(p.pre_act);
-  const u16* bias = static_cast<const u16*>(p.bias);
-  const int col_in = lane & 15, rq = lane >> 4;
+  // Epilogue (operands were swapped in the MFMA: see store_tile_bf16).
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long long col = n0 + wn + 16 * j + col_in;
-    if (col >= p.N) continue;
-    const float bv = bias ? BF16::to_f32(bias[col]) : 0.f;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j)
+      store_tile_bf16(p, acc[i][j], m0 + wm + 16 * i + (lane & 15), n0 + wn + 16 * j + 4 * (lane >> 4));
+}
+
+// =====================================================================================
+// Large-tile kernel: 256x256 output tile, 512 threads (8 waves as 2(M) x 4(N), each wave
+// 128x64 = 8x4 MFMA tiles, 128 accumulator registers), K consumed 64 at a time.
+//   * operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR staging and
+//     no ds_write instructions, which is what bounds the 128x128 kernel above (ds_write_b128
+//     moves ~79 B/clk/CU, less than a third of the read rate);
+//   * the DMA writes LDS linearly (wave base + lane*16), so the bank-conflict swizzle is applied
+//     to each lane's GLOBAL source address, and the same XOR is applied when fragments are read;
+//   * two LDS buffers (2 x 64 KiB, one workgroup per CU): the DMA of tile k+1 is issued right
+//     after the barrier that publishes tile k and lands while tile k is being multiplied;
+//   * rows / columns past the matrix edge are clamped to the last valid one (their results are
+//     never stored); K must be a multiple of 64 (no zero fill exists on the DMA path).
+// =====================================================================================
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int kThreads2 = 512;
+constexpr int kTileBytes2 = BM2 * BK2 * 2;  // 32 KiB per operand per stage
+
+// [256 rows][64 k] image, 128-byte rows: same chunk swizzle as the small kernel.
+__device__ __forceinline__ int kmajor2_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+// [64 k][256 rows] image, 512-byte rows, 32 chunks: XOR on the low four chunk bits.
+__device__ __forceinline__ int rmajor2_off(int k, int c) { return k * 512 + ((c ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)))) << 4); }
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+// Issues this wave's share of one operand tile: 4 DMA instructions of 1 KiB each.
+template <bool KMAJOR>
+__device__ __forceinline__ void dma_tile(const u16* __restrict__ base, long long ld, long long r0, long long R, long long k0,
+                                         char* lds_tile, int wid, int lane) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const long long row = m0 + wm + 16 * i + 4 * rq + e;
-        if (row >= p.M) continue;
-        float v = p.alpha * acc[i][j][e] + bv;
-        if (p.beta != 0.f) v += p.beta * BF16::to_f32(C[row * p.ldc + col]);
-        if (P) P[row * p.ldc + col] = BF16::from_f32(v);
-        C[row * p.ldc + col] = BF16::from_f32(act_fn(v, p.act));
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wid * 4 + i;  // 32 pieces of 1 KiB per tile
+    const u16* src;
+    if (KMAJOR) {
+      const int row = piece * 8 + (lane >> 3);                  // 8 rows of 128 B per piece
+      const int c = (lane & 7) ^ ((row >> 1) & 7);              // logical chunk that belongs at this physical slot
+      long long gr = r0 + row;
+      gr = gr < R ? gr : R - 1;
+      src = base + gr * ld + k0 + c * 8;
+    } else {
+      const int k = piece * 2 + (lane >> 5);                    // 2 k-rows of 512 B per piece
+      const int c = (lane & 31) ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)));
+      long long gc = r0 + c * 8;
+      gc = gc + 8 <= R ? gc : (R - 8);                          // R % 8 == 0 is required by the dispatcher
+      src = base + (k0 + k) * ld + gc;
+    }
+    char* dst = lds_tile + piece * 1024;  // wave-uniform; the hardware adds lane * 16
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 read_frag2(const char* lds, int tile_row0, int kk, int lane) {
+  if (KMAJOR) {
+    return *reinterpret_cast<const bf16x8*>(lds + kmajor2_off(tile_row0 + (lane & 15), 4 * kk + (lane >> 4)));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int k1 = 32 * kk + 8 * g + q;
+    const int c = (tile_row0 >> 3) + (pp >> 1);
+    const int sub = (pp & 1) << 3;
+    using lds_ptr = __attribute__((address_space(3))) s16x4*;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + rmajor2_off(k1, c) + sub));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + rmajor2_off(k1 + 4, c) + sub));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 stages][A tile | B tile]
+
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  // Column-major walk inside an XCD's run of tiles: consecutive workgroups share the B panel
+  // and sweep A panels, so a panel stays in that XCD's L2 while it is reused.
+  const int tn = wgid / tiles_m, tm = wgid % tiles_m;
+  const long long m0 = static_cast<long long>(tm) * BM2, n0 = static_cast<long long>(tn) * BN2;
+
+  const u16* A = static_cast<const u16*>(p.A);
+  const u16* B = static_cast<const u16*>(p.B);
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = (wid >> 2) * 128, wn = (wid & 3) * 64;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long nk = p.K / BK2;
+  dma_tile<A_KMAJOR>(A, p.lda, m0, p.M, 0, smem2, wid, lane);
+  dma_tile<B_KMAJOR>(B, p.ldb, n0, p.N, 0, smem2 + kTileBytes2, wid, lane);
+
+  for (long long kt = 0; kt < nk; ++kt) {
+    const int cur = static_cast<int>(kt & 1);
+    // Tile kt has landed for this wave's own pieces; the barrier publishes every wave's pieces
+    // and also guarantees that all waves have finished reading the other buffer.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) {
+      char* nxt = smem2 + (cur ^ 1) * 2 * kTileBytes2;
+      dma_tile<A_KMAJOR>(A, p.lda, m0, p.M, (kt + 1) * BK2, nxt, wid, lane);
+      dma_tile<B_KMAJOR>(B, p.ldb, n0, p.N, (kt + 1) * BK2, nxt + kTileBytes2, wid, lane);
+    }
+    const char* as = smem2 + cur * 2 * kTileBytes2;
+    const char* bs = as + kTileBytes2;
+#pragma unroll
+    for (int kk = 0; kk < BK2 / 32; ++kk) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag2<B_KMAJOR>(bs, wn + 16 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 fa = read_frag2<A_KMAJOR>(as, wm + 16 * i, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
       }
     }
   }
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      store_tile_bf16(p, acc[i][j], m0 + wm + 16 * i + (lane & 15), n0 + wn + 16 * j + 4 * (lane >> 4));
+}
+
+bool use_large_tile(const GemmArgs& a) {
+  if (a.K % BK2 != 0) return false;
+  if (a.M < 8 || a.N < 8) return false;
+  // enough 256x256 tiles to occupy the chip, otherwise the 128x128 kernel spreads better
+  const long long tiles = ((a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
+  return tiles >= 128;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -198,6 +366,26 @@ bool gemm_bf16_supported(const GemmArgs& a) {
 }
 
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
+  if (use_large_tile(a)) {
+    const int tm2 = static_cast<int>((a.M + BM2 - 1) / BM2), tn2 = static_cast<int>((a.N + BN2 - 1) / BN2);
+    const dim3 grid2(static_cast<unsigned>(tm2) * static_cast<unsigned>(tn2));
+    const size_t lds2 = 4 * kTileBytes2;  // 128 KiB: above the 64 KiB default, so the limit is raised per kernel
+    auto go2 = [&](auto ak, auto bk) {
+      constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
+      static bool configured = false;
+      if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2));
+        configured = true;
+      }
+      hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKM>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2);
+    };
+    if (a.a_kmajor && a.b_kmajor) go2(std::true_type{}, std::true_type{});
+    else if (a.a_kmajor && !a.b_kmajor) go2(std::true_type{}, std::false_type{});
+    else if (!a.a_kmajor && a.b_kmajor) go2(std::false_type{}, std::true_type{});
+    else go2(std::false_type{}, std::false_type{});
+    return;
+  }
   const int tiles_m = static_cast<int>((a.M + BM - 1) / BM), tiles_n = static_cast<int>((a.N + BN - 1) / BN);
   const dim3 grid(static_cast<unsigned>(tiles_m) * static_cast<unsigned>(tiles_n));
   const size_t lds = 4 * kTileBytes;

@@ -19,6 +19,14 @@ from torch.optim import Optimizer
 from .. import _ext
 
 
+def _flat_dense(t: torch.Tensor) -> torch.Tensor:
+    """1-D view over the storage of a dense tensor (any memory format, e.g. channels-last conv
+    weights); the update is elementwise, so only a consistent element order matters."""
+    if t.is_contiguous():
+        return t
+    return t.as_strided((t.numel(),), (1,), t.storage_offset())
+
+
 class FusedAdamW(Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  master_weights: bool = False, max_grad_norm: Optional[float] = None):
@@ -95,9 +103,19 @@ class FusedAdamW(Optimizer):
             step_before = int(states[0]["step"].item()) if gi not in self._hparams else 0
             hp = self._device_hparams(gi, group, ps[0].device, step_before)
             C.adamw_tick(hp)
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            C.adamw_step(ps, grads, [s["exp_avg"] for s in states], [s["exp_avg_sq"] for s in states],
-                         [s.get("master") for s in states], hp, grad_scale)
+            pv, gv, mv, vv, wv = [], [], [], [], []
+            for p, st in zip(ps, states):
+                g = p.grad
+                if not p.is_non_overlapping_and_dense():
+                    raise RuntimeError("FusedAdamW: parameters must be dense (contiguous in some memory format)")
+                if g.stride() != p.stride():
+                    g = torch.empty_like(p).copy_(g)  # bring the gradient into the parameter's element order
+                pv.append(_flat_dense(p))
+                gv.append(_flat_dense(g))
+                mv.append(_flat_dense(st["exp_avg"]))
+                vv.append(_flat_dense(st["exp_avg_sq"]))
+                wv.append(_flat_dense(st["master"]) if "master" in st else None)
+            C.adamw_step(pv, gv, mv, vv, wv, hp, grad_scale)
             for s in states:
                 s["step"] += 1
         return loss
@@ -109,7 +127,7 @@ class FusedAdamW(Optimizer):
             self._clip = {"sumsq": z(), "coef": z(), "norm": z()}
         c = self._clip
         c["sumsq"].zero_()
-        C.grad_sumsq([g if g.is_contiguous() else g.contiguous() for g in grads], c["sumsq"])
+        C.grad_sumsq([_flat_dense(g) if g.is_non_overlapping_and_dense() else g.contiguous() for g in grads], c["sumsq"])
         C.clip_coef(c["sumsq"], float(self.max_grad_norm), c["coef"], c["norm"])
         self.last_grad_norm = c["norm"]
         return c["coef"]

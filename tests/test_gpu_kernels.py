@@ -338,3 +338,36 @@ def test_layernorm(rows, cols, dtype):
     torch.testing.assert_close(xs.grad.double(), xr.grad, **t)
     torch.testing.assert_close(gs.grad.double(), gr.grad, **tg)
     torch.testing.assert_close(bs.grad.double(), br.grad, **tg)
+
+
+@pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 128), (4000, 2056, 192), (2304, 3848, 64)])
+def test_gemm_bf16_large_tile_kernel_exact_integers(a_k, b_k, M, N, K):
+    """Shapes with >= 128 tiles of 256x256 and K % 64 == 0 take the LDS-DMA kernel; small-integer
+    operands make every product and partial sum exact, so any layout / swizzle / clamp error shows
+    up as a mismatch (outputs stay below 256 in magnitude, exactly representable in bf16)."""
+    torch.manual_seed(M + N + K)
+    Af = torch.randint(-2, 3, (M, K), device=DEV).float()
+    Bf = torch.randint(-1, 2, (K, N), device=DEV).float()
+    # make rows / columns distinguishable so a permutation of rows or columns cannot cancel out
+    Af[:, 0] = (torch.arange(M, device=DEV) % 5 - 2).float()
+    Bf[0, :] = (torch.arange(N, device=DEV) % 3 - 1).float()
+    Aop = (Af if a_k else Af.t().contiguous()).bfloat16()
+    Bop = (Bf.t().contiguous() if b_k else Bf.contiguous()).bfloat16()
+    out = C().gemm(Aop, Bop, a_k, b_k)
+    ref = Af.double() @ Bf.double()
+    assert ref.abs().max() < 256
+    assert torch.equal(out.double(), ref)
+
+
+def test_gemm_bf16_large_tile_fused_epilogue():
+    torch.manual_seed(4)
+    M, N, K = 4096, 2048, 256
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    w = (torch.randn(N, K, device=DEV) / 16).bfloat16()
+    b = torch.randn(N, device=DEV).bfloat16()
+    for act, fn in ((1, torch.relu), (2, torch.nn.functional.gelu)):
+        y, pre = C().linear_forward(x, w, b, act, True)
+        ref_pre = x.double() @ w.double().t() + b.double()
+        torch.testing.assert_close(pre.double(), ref_pre, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(y.double(), fn(ref_pre), rtol=2e-2, atol=2e-2)

@@ -137,5 +137,18 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, cons
                           const float* rstd, void* dx, void* dgamma, void* dbeta, float* workspace,
                           long long rows, long long cols, int dtype, hipStream_t stream);
 
+// ------------------------------------------------------------------ causal attention (head dim 64, bf16)
+// q/k/v element (b, t, h, d) lives at ptr[(b*T + t) * row_stride + h*64 + d] (a packed
+// [B, T, 3, H, 64] projection has row_stride = 3*H*64 and k = q + H*64, v = q + 2*H*64).
+// o / do are [B, T, H, 64] contiguous; lse and delta are [B, H, T] fp32.
+bool attention_supported(long long T, long long head_dim, long long row_stride);
+void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                          long long row_stride, int B, int H, int T, float softmax_scale,
+                          hipStream_t stream);
+void launch_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                          const float* lse, float* delta, void* dq, void* dk, void* dv,
+                          long long row_stride, long long grad_row_stride, int B, int H, int T,
+                          float softmax_scale, hipStream_t stream);
+
 }  // namespace kernels
 }  // namespace dpa

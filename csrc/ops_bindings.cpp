@@ -462,9 +462,53 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tenso
   return {dx, dgamma, dbeta};
 }
 
+// ------------------------------------------------------------------ attention
+// qkv: [B, T, 3*H*64] bf16 (q | k | v along the last dimension).  Returns (o [B,T,H*64], lse [B,H,T]).
+std::tuple<Tensor, Tensor> attention_forward(Tensor qkv, int64_t n_head, double softmax_scale) {
+  check_gpu(qkv, "qkv");
+  TORCH_CHECK(qkv.dim() == 3 && qkv.scalar_type() == at::kBFloat16, "attention_forward: qkv must be bf16 [B, T, 3*C]");
+  const int64_t B = qkv.size(0), T = qkv.size(1), C3 = qkv.size(2);
+  TORCH_CHECK(C3 % 3 == 0 && (C3 / 3) % n_head == 0, "attention_forward: last dimension must be 3 * n_head * head_dim");
+  const int64_t Cd = C3 / 3, hd = Cd / n_head;
+  TORCH_CHECK(kernels::attention_supported(T, hd, C3), "attention_forward: needs head_dim 64 and T a multiple of 128 (got head_dim ", hd, ", T ", T, ")");
+  Tensor o = at::empty({B, T, Cd}, qkv.options());
+  Tensor lse = at::empty({B, n_head, T}, qkv.options().dtype(at::kFloat));
+  DevGuard guard(qkv);
+  const char* base = static_cast<const char*>(qkv.data_ptr());
+  kernels::launch_attention_fwd(base, base + Cd * 2, base + 2 * Cd * 2, o.data_ptr(), lse.data_ptr<float>(), C3, static_cast<int>(B),
+                                static_cast<int>(n_head), static_cast<int>(T), static_cast<float>(softmax_scale), stream_of(qkv));
+  return {o, lse};
+}
+
+// Returns dqkv [B, T, 3*C] given the forward's inputs / outputs and do [B, T, C].
+Tensor attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t n_head, double softmax_scale) {
+  check_gpu(d_o, "do");
+  check_gpu(qkv, "qkv");
+  check_gpu(o, "o");
+  check_gpu(lse, "lse");
+  TORCH_CHECK(qkv.dim() == 3 && qkv.scalar_type() == at::kBFloat16 && d_o.scalar_type() == at::kBFloat16 && o.scalar_type() == at::kBFloat16,
+              "attention_backward: bf16 tensors expected");
+  const int64_t B = qkv.size(0), T = qkv.size(1), C3 = qkv.size(2), Cd = C3 / 3, hd = Cd / n_head;
+  TORCH_CHECK(d_o.sizes() == o.sizes() && o.size(0) == B && o.size(1) == T && o.size(2) == Cd, "attention_backward: shape mismatch");
+  TORCH_CHECK(lse.scalar_type() == at::kFloat && lse.numel() == B * n_head * T, "attention_backward: lse must be float32 [B, H, T]");
+  TORCH_CHECK(kernels::attention_supported(T, hd, C3), "attention_backward: unsupported shape");
+  Tensor dqkv = at::empty_like(qkv);
+  Tensor delta = at::empty({B, n_head, T}, lse.options());
+  DevGuard guard(qkv);
+  const char* base = static_cast<const char*>(qkv.data_ptr());
+  char* gbase = static_cast<char*>(dqkv.data_ptr());
+  kernels::launch_attention_bwd(base, base + Cd * 2, base + 2 * Cd * 2, o.data_ptr(), d_o.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(),
+                                gbase, gbase + Cd * 2, gbase + 2 * Cd * 2, C3, C3, static_cast<int>(B), static_cast<int>(n_head),
+                                static_cast<int>(T), static_cast<float>(softmax_scale), stream_of(qkv));
+  return dqkv;
+}
+
 }  // namespace
 
 void init_ops(py::module_& m) {
+  m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("n_head"), py::arg("softmax_scale"));
+  m.def("attention_backward", &attention_backward);
+  m.def("attention_supported", [](int64_t T, int64_t hd, int64_t rs) { return kernels::attention_supported(T, hd, rs); });
   m.def("multi_copy_scale", &multi_copy_scale, py::arg("srcs"), py::arg("dsts"), py::arg("scale") = 1.0);
   m.def("scale_inplace", &scale_inplace);
   m.def("adamw_tick", &adamw_tick);

@@ -6,7 +6,8 @@ family exists because the framework's throughput bar is defined on it.  Hot ops 
 native kernels: layer norm, the MLP up-projection with fused bias + GELU epilogue, the loss
 (fused softmax cross-entropy + accuracy over a vocabulary padded to a multiple of 64 so
 every logits row is 16-byte aligned, gradient written in place over the logits), and the
-optimizer (FusedAdamW).  Attention uses torch's fused scaled-dot-product kernel.
+optimizer (FusedAdamW).  Attention runs on the native flash-attention kernels directly on the
+packed q|k|v projection (``attention_impl="sdpa"`` selects torch's kernel instead).
 
 ``linear_impl``: ``"native"`` routes every projection through the hand-written MFMA GEMM;
 ``"library"`` runs the plain GEMMs on the vendor library and everything around them
@@ -24,6 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops.attention import causal_attention_qkvpacked
 from ..ops.cross_entropy import softmax_cross_entropy
 from ..ops.layernorm import LayerNorm
 from ..ops.linear import library_linear_bias_act, linear_bias_act
@@ -41,6 +43,7 @@ class GPT2Config:
     linear_impl: str = "auto"     # native | library | auto
     inplace_loss_backward: bool = True
     native_ops: bool = True       # False: stock torch layer norm / GELU / cross-entropy (comparison baseline)
+    attention_impl: str = "auto"  # auto | native | sdpa
 
     @property
     def padded_vocab_size(self) -> int:
@@ -83,18 +86,12 @@ class CausalSelfAttention(nn.Module):
         super().__init__()
         assert cfg.n_embd % cfg.n_head == 0
         self.n_head = cfg.n_head
+        self.impl = cfg.attention_impl if cfg.native_ops else "sdpa"
         self.c_attn = _Proj(cfg.n_embd, 3 * cfg.n_embd, cfg.bias, cfg.linear_impl)
         self.c_proj = _Proj(cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
 
     def forward(self, x):
-        B, T, Cd = x.shape
-        q, k, v = self.c_attn(x).split(Cd, dim=2)
-        hd = Cd // self.n_head
-        q = q.view(B, T, self.n_head, hd).transpose(1, 2)
-        k = k.view(B, T, self.n_head, hd).transpose(1, 2)
-        v = v.view(B, T, self.n_head, hd).transpose(1, 2)
-        y = F.scaled_dot_product_attention(q, k, v, is_causal=True)
-        y = y.transpose(1, 2).reshape(B, T, Cd)
+        y = causal_attention_qkvpacked(self.c_attn(x), self.n_head, impl=self.impl)
         return self.c_proj(y)
 
 

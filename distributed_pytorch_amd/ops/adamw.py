@@ -19,6 +19,19 @@ from torch.optim import Optimizer
 from .. import _ext
 
 
+def _is_dense(t: torch.Tensor) -> bool:
+    """True when the tensor's elements occupy one gap-free, non-overlapping run of storage in
+    some dimension order (contiguous, channels-last, permuted views of either)."""
+    if t.is_contiguous():
+        return True
+    expect = 1
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.shape, t.stride()) if sz != 1), key=lambda x: x[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
 def _flat_dense(t: torch.Tensor) -> torch.Tensor:
     """1-D view over the storage of a dense tensor (any memory format, e.g. channels-last conv
     weights); the update is elementwise, so only a consistent element order matters."""
@@ -106,7 +119,7 @@ class FusedAdamW(Optimizer):
             pv, gv, mv, vv, wv = [], [], [], [], []
             for p, st in zip(ps, states):
                 g = p.grad
-                if not p.is_non_overlapping_and_dense():
+                if not _is_dense(p):
                     raise RuntimeError("FusedAdamW: parameters must be dense (contiguous in some memory format)")
                 if g.stride() != p.stride():
                     g = torch.empty_like(p).copy_(g)  # bring the gradient into the parameter's element order
@@ -127,7 +140,7 @@ class FusedAdamW(Optimizer):
             self._clip = {"sumsq": z(), "coef": z(), "norm": z()}
         c = self._clip
         c["sumsq"].zero_()
-        C.grad_sumsq([_flat_dense(g) if g.is_non_overlapping_and_dense() else g.contiguous() for g in grads], c["sumsq"])
+        C.grad_sumsq([_flat_dense(g) if _is_dense(g) else g.contiguous() for g in grads], c["sumsq"])
         C.clip_coef(c["sumsq"], float(self.max_grad_norm), c["coef"], c["norm"])
         self.last_grad_norm = c["norm"]
         return c["coef"]

@@ -1,0 +1,75 @@
+"""Causal self-attention on a packed q|k|v projection.
+
+``causal_attention_qkvpacked(qkv, n_head)`` takes the [B, T, 3*C] output of the fused
+query/key/value projection as it comes out of the GEMM and returns [B, T, C] ready for the
+output projection: the kernels read the three operands with their native row stride and write
+heads back interleaved, so no head split / transpose / reshape copies exist in either
+direction, and the backward writes dq|dk|dv straight into one [B, T, 3*C] tensor (the
+gradient of the projection output).
+
+On gfx950 the work runs on hand-written flash-attention kernels (bf16 MFMA, online softmax,
+recompute-based backward without atomics) for head size 64 and T a multiple of 128; other
+shapes, dtypes and CPU tensors use torch's scaled-dot-product attention.
+
+The reference contains no attention (its model is two linear layers, reference
+min_DDP.py:41-49); this op serves the GPT-2 benchmark configuration.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import _ext
+
+
+class _FlashQKV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, n_head, scale):
+        C = _ext.C()
+        o, lse = C.attention_forward(qkv, n_head, scale)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.n_head, ctx.scale = n_head, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, lse = ctx.saved_tensors
+        d_o = d_o if d_o.is_contiguous() else d_o.contiguous()
+        return _ext.C().attention_backward(d_o, qkv, o, lse, ctx.n_head, ctx.scale), None, None
+
+
+def native_attention_supported(qkv: torch.Tensor, n_head: int) -> bool:
+    if not (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.is_contiguous()):
+        return False
+    if not _ext.have_C():
+        return False
+    _, T, C3 = qkv.shape
+    if C3 % (3 * n_head):
+        return False
+    return bool(_ext.C().attention_supported(T, C3 // 3 // n_head, C3))
+
+
+def causal_attention_qkvpacked(qkv: torch.Tensor, n_head: int, softmax_scale: Optional[float] = None,
+                               impl: str = "auto") -> torch.Tensor:
+    """qkv: [B, T, 3*C] (q | k | v along the last dimension) -> [B, T, C].
+
+    impl: "auto" (native kernels when the shape qualifies), "native" (raise otherwise), "sdpa".
+    """
+    B, T, C3 = qkv.shape
+    Cd = C3 // 3
+    hd = Cd // n_head
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(hd)
+    if impl != "sdpa":
+        if torch.is_autocast_enabled() and qkv.is_cuda and qkv.dtype != torch.bfloat16:
+            qkv = qkv.to(torch.get_autocast_dtype("cuda"))
+        if native_attention_supported(qkv, n_head):
+            return _FlashQKV.apply(qkv, n_head, scale)
+        if impl == "native":
+            raise RuntimeError(f"native attention does not cover qkv {tuple(qkv.shape)} {qkv.dtype} on {qkv.device} "
+                               f"with {n_head} heads (needs bf16, head size 64, T % 128 == 0, contiguous)")
+    q, k, v = (t.view(B, T, n_head, hd).transpose(1, 2) for t in qkv.split(Cd, dim=2))
+    y = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=scale)
+    return y.transpose(1, 2).reshape(B, T, Cd)

@@ -278,8 +278,10 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int tile_row0, int
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, int tiles_m, int tiles_n) {
+// SPLIT: blockIdx.y selects a contraction range of `k_iters` steps; raw fp32 partial tiles go to
+// p.workspace[blockIdx.y][M][N] (16-byte stores) and splitk_reduce_kernel finishes the product.
+template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT>
+__global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters) {
   extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 stages][A tile | B tile]
 
   const int nwg = tiles_m * tiles_n;
@@ -303,12 +305,14 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const long long nk = p.K / BK2;
-  dma_tile<A_KMAJOR>(A, p.lda, m0, p.M, 0, smem2, wid, lane);
-  dma_tile<B_KMAJOR>(B, p.ldb, n0, p.N, 0, smem2 + kTileBytes2, wid, lane);
+  const long long nk_all = p.K / BK2;
+  const long long kt0 = SPLIT ? static_cast<long long>(blockIdx.y) * k_iters : 0;
+  const long long nk = SPLIT ? (kt0 + k_iters < nk_all ? kt0 + k_iters : nk_all) : nk_all;
+  dma_tile<A_KMAJOR>(A, p.lda, m0, p.M, kt0 * BK2, smem2, wid, lane);
+  dma_tile<B_KMAJOR>(B, p.ldb, n0, p.N, kt0 * BK2, smem2 + kTileBytes2, wid, lane);
 
-  for (long long kt = 0; kt < nk; ++kt) {
-    const int cur = static_cast<int>(kt & 1);
+  for (long long kt = kt0; kt < nk; ++kt) {
+    const int cur = static_cast<int>((kt - kt0) & 1);
     // Tile kt has landed for this wave's own pieces; the barrier publishes every wave's pieces
     // and also guarantees that all waves have finished reading the other buffer.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -334,11 +338,38 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
     }
   }
 
+  if (SPLIT) {
+    float* ws = p.workspace + static_cast<long long>(blockIdx.y) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long row = m0 + wm + 16 * i + (lane & 15), col0 = n0 + wn + 16 * j + 4 * (lane >> 4);
+        if (row < p.M && col0 < p.N) *reinterpret_cast<f32x4*>(ws + row * p.N + col0) = acc[i][j];  // N % 4 == 0 on this path
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       store_tile_bf16(p, acc[i][j], m0 + wm + 16 * i + (lane & 15), n0 + wn + 16 * j + 4 * (lane >> 4));
+}
+
+// Sums the split-K partials in index order (deterministic) and applies the regular epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
+  const long long quad = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;  // 4 consecutive columns
+  const long long nq = p.N >> 2;
+  if (quad >= p.M * nq) return;
+  const long long row = quad / nq, col0 = (quad % nq) << 2;
+  const long long plane = p.M * p.N;
+  const float* src = p.workspace + row * p.N + col0;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+  for (int s = 1; s < p.split_k; ++s) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + s * plane);
+    acc += v;
+  }
+  store_tile_bf16(p, acc, row, col0);
 }
 
 bool use_large_tile(const GemmArgs& a) {
@@ -353,6 +384,21 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+int gemm_bf16_split_k(const GemmArgs& a) {
+  if (!gemm_bf16_supported(a)) return 1;
+  if (a.K % BK2 != 0 || a.N % 4 != 0 || a.M < 8 || a.N < 8) return 1;
+  const long long tiles = ((a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
+  const long long nk = a.K / BK2;
+  if (tiles >= 128 || nk < 32) return 1;
+  // One workgroup per CU (128 KiB of LDS each): aim for one full wave of 256 workgroups, with at
+  // least 16 contraction steps per range so the pipeline prologue stays amortised.
+  long long s = 256 / tiles;
+  if (s > nk / 16) s = nk / 16;
+  if (s < 2) return 1;
+  const long long iters = (nk + s - 1) / s;
+  return static_cast<int>((nk + iters - 1) / iters);
+}
+
 bool gemm_bf16_supported(const GemmArgs& a) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
   // 16-byte global loads: contiguous extents and leading dimensions in multiples of 8 elements.
@@ -366,19 +412,30 @@ bool gemm_bf16_supported(const GemmArgs& a) {
 }
 
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
-  if (use_large_tile(a)) {
+  const bool split = a.split_k > 1 && a.workspace != nullptr;
+  if (split || use_large_tile(a)) {
     const int tm2 = static_cast<int>((a.M + BM2 - 1) / BM2), tn2 = static_cast<int>((a.N + BN2 - 1) / BN2);
-    const dim3 grid2(static_cast<unsigned>(tm2) * static_cast<unsigned>(tn2));
+    const long long nk = a.K / BK2;
+    const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);
+    const dim3 grid2(static_cast<unsigned>(tm2) * static_cast<unsigned>(tn2), split ? static_cast<unsigned>(a.split_k) : 1u);
     const size_t lds2 = 4 * kTileBytes2;  // 128 KiB: above the 64 KiB default, so the limit is raised per kernel
     auto go2 = [&](auto ak, auto bk) {
       constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
       static bool configured = false;
       if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2));
         configured = true;
       }
-      hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKM>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2);
+      if (split) {
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKM, true>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
+        const long long quads = a.M * (a.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, stream, a);
+      } else {
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKM, false>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
+      }
     };
     if (a.a_kmajor && a.b_kmajor) go2(std::true_type{}, std::true_type{});
     else if (a.a_kmajor && !a.b_kmajor) go2(std::true_type{}, std::false_type{});

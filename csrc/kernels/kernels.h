@@ -96,7 +96,16 @@ struct GemmArgs {
   int act;
   float alpha;
   float beta;        // C = alpha*acc + beta*C_old (beta != 0 only with act == none, no bias)
+  // Split-K (bf16 only): with split_k > 1 the contraction is cut into split_k ranges computed by
+  // separate workgroups into fp32 partials `workspace[split_k][M][N]`, summed in a fixed order by
+  // a second kernel that applies the epilogue.  Both are set by the caller from
+  // gemm_bf16_split_k(); zero / nullptr means a single pass.
+  float* workspace;
+  int split_k;
 };
+// Number of contraction ranges worth using for this product (1 = do not split): > 1 when the
+// output has too few 256x256 tiles to occupy the chip but a long contraction (weight gradients).
+int gemm_bf16_split_k(const GemmArgs& a);
 bool gemm_f32_supported(const GemmArgs& a);
 void launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 bool gemm_bf16_supported(const GemmArgs& a);

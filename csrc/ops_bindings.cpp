@@ -252,9 +252,22 @@ bool gemm_path_ok(const kernels::GemmArgs& a, int dt) {
   return dt == kernels::kF32 ? kernels::gemm_f32_supported(a) : (dt == kernels::kBF16 ? kernels::gemm_bf16_supported(a) : false);
 }
 
-void run_gemm(const kernels::GemmArgs& a, int dt, hipStream_t s) {
-  if (dt == kernels::kF32) kernels::launch_gemm_f32(a, s);
-  else kernels::launch_gemm_bf16(a, s);
+// `like` supplies the device for the split-K workspace (fp32 partials, caching allocator).
+void run_gemm(const kernels::GemmArgs& a, int dt, hipStream_t s, const Tensor& like) {
+  if (dt == kernels::kF32) {
+    kernels::launch_gemm_f32(a, s);
+    return;
+  }
+  const int split = kernels::gemm_bf16_split_k(a);
+  if (split > 1) {
+    kernels::GemmArgs b = a;
+    Tensor ws = at::empty({static_cast<int64_t>(split) * a.M * a.N}, like.options().dtype(at::kFloat));
+    b.workspace = ws.data_ptr<float>();
+    b.split_k = split;
+    kernels::launch_gemm_bf16(b, s);
+    return;
+  }
+  kernels::launch_gemm_bf16(a, s);
 }
 
 // Which kernel family a y = x W^T (+b) product of this shape runs on.
@@ -302,7 +315,7 @@ std::tuple<Tensor, c10::optional<Tensor>> linear_forward(Tensor x, Tensor w, c10
       a.pre_act = pre->data_ptr();
     }
     TORCH_CHECK(gemm_path_ok(a, dt), "linear_forward: shape M=", M, " N=", N, " K=", K, " is not supported by the MFMA GEMM for dtype ", x.scalar_type());
-    run_gemm(a, dt, s);
+    run_gemm(a, dt, s, x);
   }
   return {y, pre};
 }
@@ -343,14 +356,14 @@ std::tuple<c10::optional<Tensor>, Tensor, c10::optional<Tensor>> linear_backward
     a.A = g.data_ptr(); a.B = x.data_ptr(); a.C = dW.data_ptr();
     a.M = N; a.N = K; a.K = M; a.lda = N; a.ldb = K; a.ldc = K; a.a_kmajor = 0; a.b_kmajor = 0; a.alpha = 1.f;
     TORCH_CHECK(gemm_path_ok(a, dt), "linear_backward: weight-gradient shape not supported by the MFMA GEMM");
-    run_gemm(a, dt, s);
+    run_gemm(a, dt, s, g);
     if (need_dx) {
       // dx[M,K] = g W : contraction over N; A = g is contraction-contiguous, B = W is stored [N(contraction), K].
       kernels::GemmArgs b{};
       b.A = g.data_ptr(); b.B = w.data_ptr(); b.C = dx->data_ptr();
       b.M = M; b.N = K; b.K = N; b.lda = N; b.ldb = K; b.ldc = K; b.a_kmajor = 1; b.b_kmajor = 0; b.alpha = 1.f;
       TORCH_CHECK(gemm_path_ok(b, dt), "linear_backward: input-gradient shape not supported by the MFMA GEMM");
-      run_gemm(b, dt, s);
+      run_gemm(b, dt, s, g);
     }
     if (need_db) {
       Tensor ws = at::empty({kernels::colreduce_workspace(M, N)}, fopt);
@@ -414,7 +427,7 @@ Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tens
   const int dt = kdtype(A);
   TORCH_CHECK(gemm_path_ok(a, dt), "gemm: shape M=", M, " N=", N, " K=", K, " not supported for dtype ", A.scalar_type());
   DevGuard guard(A);
-  run_gemm(a, dt, stream_of(A));
+  run_gemm(a, dt, stream_of(A), A);
   return C;
 }
 
@@ -508,6 +521,13 @@ Tensor attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t 
 void init_ops(py::module_& m) {
   m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("n_head"), py::arg("softmax_scale"));
   m.def("attention_backward", &attention_backward);
+  m.def("gemm_bf16_split_k", [](int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor) {
+    kernels::GemmArgs a{};
+    a.M = M; a.N = N; a.K = K;
+    a.a_kmajor = a_kmajor; a.b_kmajor = b_kmajor;
+    a.lda = a_kmajor ? K : M; a.ldb = b_kmajor ? K : N; a.ldc = N;
+    return kernels::gemm_bf16_split_k(a);
+  }, "contraction ranges the bf16 GEMM would use for an [M,K]x[K,N] product (1 = single pass)");
   m.def("attention_supported", [](int64_t T, int64_t hd, int64_t rs) { return kernels::attention_supported(T, hd, rs); });
   m.def("multi_copy_scale", &multi_copy_scale, py::arg("srcs"), py::arg("dsts"), py::arg("scale") = 1.0);
   m.def("scale_inplace", &scale_inplace);

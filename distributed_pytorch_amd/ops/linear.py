@@ -114,7 +114,14 @@ class _LibraryGemmLinear(torch.autograd.Function):
             if ctx.has_bias:
                 db = C.colsum(dy)
         dx = g @ weight if ctx.needs_input_grad[0] else None
-        dw = g.t() @ x
+        # Weight gradient: [N_out, K_in] is a handful of output tiles with the whole token count as
+        # contraction length.  Where the native GEMM would split the contraction over the chip
+        # (few tiles, long K) it is the faster kernel; otherwise the vendor GEMM runs.
+        if (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and x.is_contiguous()
+                and C.gemm_bf16_split_k(g.shape[1], x.shape[1], g.shape[0], False, False) > 1):
+            dw = C.gemm(g, x, False, False)
+        else:
+            dw = g.t() @ x
         return dx, dw, db, None
 
 

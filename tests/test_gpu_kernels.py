@@ -451,3 +451,24 @@ def test_attention_op_autograd_and_fallback():
     assert causal_attention_qkvpacked(odd, 1).shape == (1, 100, 64)
     with pytest.raises(RuntimeError):
         causal_attention_qkvpacked(odd, 1, impl="native")
+
+
+@pytest.mark.parametrize("a_k,b_k", [(False, False), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 2048), (520, 1032, 3072)])
+def test_gemm_bf16_split_k_exact_integers(a_k, b_k, M, N, K):
+    """Few output tiles + long contraction (the weight-gradient shape) takes the split-K path:
+    fp32 partials per contraction range, summed in a fixed order.  Integer operands keep every
+    partial exact, so the result must equal the fp64 product bit for bit."""
+    torch.manual_seed(K + M)
+    Af = torch.randint(-1, 2, (M, K), device=DEV).float()
+    Bf = torch.randint(-1, 2, (K, N), device=DEV).float()
+    Af[:, 0] = (torch.arange(M, device=DEV) % 3 - 1).float()
+    Bf[0, :] = (torch.arange(N, device=DEV) % 3 - 1).float()
+    Aop = (Af if a_k else Af.t().contiguous()).bfloat16()
+    Bop = (Bf.t().contiguous() if b_k else Bf.contiguous()).bfloat16()
+    out = C().gemm(Aop, Bop, a_k, b_k)
+    ref = Af.double() @ Bf.double()
+    assert ref.abs().max() < 256
+    assert torch.equal(out.double(), ref)
+    again = C().gemm(Aop, Bop, a_k, b_k)
+    assert torch.equal(out, again)  # deterministic reduction order

@@ -80,29 +80,145 @@ struct AttnParams {
   float scale_log2;      // softmax scale * log2(e)
 };
 
-// Loads this thread's two 16-byte pieces of a [64][64] tile (rows = keys key0..key0+63).
-__device__ __forceinline__ void load_tile_regs(const u16* base, long long row_stride, int key0, u32x4 (&r)[2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int id = threadIdx.x + i * kThreads;
-    r[i] = *reinterpret_cast<const u32x4*>(base + static_cast<long long>(key0 + (id >> 3)) * row_stride + ((id & 7) << 3));
-  }
+// Workgroup -> (block index within the head, batch*head).  Hardware hands consecutive workgroup ids
+// to the 8 XCDs round-robin and every XCD has its own L2, so the blocks of one head -- which all
+// stream the same K / V (or Q / dO) rows -- are given ids that land on ONE XCD: the id is mapped
+// bijectively to v = (position of this id inside its XCD's run), and v is split as
+// (head = v / blocks_per_head, block = v % blocks_per_head).
+__device__ __forceinline__ void head_block_of_workgroup(int blocks_per_head, int& block, int& bh) {
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  bh = v / blocks_per_head;
+  block = v - bh * blocks_per_head;
 }
-template <bool IS_V>
-__device__ __forceinline__ void store_tile_regs(char* tile, const u32x4 (&r)[2]) {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// Maximum of a strip's 16 scaled scores.  The inputs are products (already canonical floats), so the
+// compiler emits bare v_max3_f32 without the NaN-quieting moves it wraps around fmaxf of raw
+// matrix-core outputs.  (Inline-asm max instructions are not an option here: the hazard
+// recogniser does not see inside them, and a VALU read too soon after an MFMA write returns stale
+// accumulator data.)
+__device__ __forceinline__ float max16(const f32x2 (&t)[8]) {
+  float m = fmaxf(fmaxf(t[0][0], t[0][1]), t[1][0]);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int id = threadIdx.x + i * kThreads;
-    const int off = IS_V ? v_off(id >> 3, id & 7) : k_off(id >> 3, id & 7);
-    *reinterpret_cast<u32x4*>(tile + off) = r[i];
-  }
+  for (int i = 1; i < 7; ++i) m = fmaxf(fmaxf(m, t[i][1]), t[i + 1][0]);
+  return fmaxf(m, t[7][1]);
 }
+// Combine a value across the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) with the
+// gfx950 row-swap instructions: two VALU ops per step instead of an LDS round trip (ds_bpermute).
+__device__ __forceinline__ float groups_max(float x) {
+  const unsigned xi = __float_as_uint(x);
+  const u32x2 a = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  const float m1 = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned mi = __float_as_uint(m1);
+  const u32x2 b = __builtin_amdgcn_permlane16_swap(mi, mi, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float groups_sum(float x) {
+  const unsigned xi = __float_as_uint(x);
+  const u32x2 a = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  const float s1 = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned si = __float_as_uint(s1);
+  const u32x2 b = __builtin_amdgcn_permlane16_swap(si, si, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// s_waitcnt vmcnt(0) as a real instruction the compiler's wait-count bookkeeping sees: placed after
+// the loop-invariant operand loads so that waits inside the loop only cover the loop's own loads
+// (the memory counter retires in order; without this every iteration drains the prefetch early).
+__device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // Raw v_exp_f32 (2^x): inputs here are <= 0 or -inf, where the instruction is exact enough and
 // needs none of the denormal-range fix-ups of exp2f().
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+// Waits until at most N of this wave's vector-memory operations (LDS-DMA included) are outstanding;
+// emitted as a real s_waitcnt so the compiler's own bookkeeping sees it.
+template <int N>
+__device__ __forceinline__ void wait_vmem_at_most() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// A [rows][64] bf16 tile image is filled by LDS-DMA (global_load_lds_dwordx4: each lane fetches 16
+// bytes and the hardware writes the wave's 64 pieces to 1 KiB of consecutive LDS, i.e. 8 image
+// rows).  The destination order is fixed, so the bank swizzle is applied on the SOURCE side: the
+// lane that lands in physical chunk pc of row r fetches the logical chunk that belongs there.
+// Returns the per-lane source pointer of 1-KiB piece `piece` (rows 8*piece .. 8*piece+7) of a tile
+// whose first row is `base` (row stride in elements); V_SWIZZLE selects the v_off image.
+template <bool V_SWIZZLE>
+__device__ __forceinline__ const u16* dma_src(const u16* base, long long row_stride, int piece, int lane) {
+  const int r = piece * 8 + (lane >> 3), pc = lane & 7;
+  const int c = V_SWIZZLE ? (pc ^ (2 * ((r >> 1) & 3))) : (pc ^ ((r >> 1) & 7));
+  return base + static_cast<long long>(r) * row_stride + c * 8;
+}
+// Issued through inline assembly on purpose: the compiler orders every LDS read it cannot prove
+// disjoint (all transposing reads, for a start) behind ALL outstanding LDS-DMA it knows of with an
+// s_waitcnt vmcnt(0), which would serialise the ring.  Ordering is explicit here instead: a counted
+// vmcnt wait plus a workgroup barrier before a stage is read, a barrier after its last read before
+// it is requested again.  `lds_addr` is the wave-uniform LDS byte address of the 1-KiB piece.
+__device__ __forceinline__ void dma_16B(const u16* src, unsigned lds_addr) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(a) : "memory");
+}
+__device__ __forceinline__ unsigned lds_address(const char* p) {
+  return __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)p)));
+}
+
+// Online-softmax update of one 16-query strip: scores s (S^T accumulators of the strip's four
+// 16-key tiles) -> bf16 probabilities packed as the two B operands of the P.V product.
+template <bool MASK>
+__device__ __forceinline__ void softmax_strip(f32x4 (&s)[4], f32x4 (&o)[4], float& m, float& l, bf16x8 (&pf)[2], int rel, float c) {
+  if (MASK) {  // key index 16t + e of this lane group is allowed while 16t + e <= rel
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (16 * t + e > rel) s[t][e] = -__builtin_huge_valf();
+  }
+  // scaled scores (log2 domain), row maximum, then one packed subtract + exp per pair
+  const f32x2 cc = {c, c};
+  f32x2 t2[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) t2[2 * t + h2] = f32x2{s[t][2 * h2], s[t][2 * h2 + 1]} * cc;  // v_pk_mul_f32
+  const float mx = groups_max(max16(t2));
+  const float m_new = fmaxf(m, mx);
+  const float alpha = fast_exp2(m - m_new);
+  m = m_new;
+  const f32x2 mm = {m_new, m_new};
+  f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x2 x = t2[i] - mm;  // v_pk_add_f32
+    x[0] = fast_exp2(x[0]);
+    x[1] = fast_exp2(x[1]);
+    ps2 += x;
+    t2[i] = x;
+  }
+  l = fmaf(l, alpha, ps2[0] + ps2[1]);  // per-lane partial sum; combined across the 4 lane groups at the end
+  if (__any(alpha != 1.f)) {            // the running maximum moved for some query of this wave
+#pragma unroll
+    for (int td = 0; td < 4; ++td)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[td][e] *= alpha;
+  }
+#pragma unroll
+  for (int sk = 0; sk < 2; ++sk)
+    pf[sk] = pack8(t2[4 * sk][0], t2[4 * sk][1], t2[4 * sk + 1][0], t2[4 * sk + 1][1], t2[4 * sk + 2][0], t2[4 * sk + 2][1],
+                   t2[4 * sk + 3][0], t2[4 * sk + 3][1]);
+}
+
 // One key tile for both 16-query strips of a wave.  MASK = the tile crosses the diagonal.
+// (Issuing both strips' score products before the first softmax, to keep the matrix pipe busy under
+// the VALU work of the same wave, was measured: it costs 27 more registers and gains nothing at
+// three waves per SIMD.)
 template <bool MASK>
 __device__ __forceinline__ void fwd_tile(const char* ks, const char* vs, const bf16x8 (&qf)[2][2], f32x4 (&o)[2][4], float (&m)[2],
                                          float (&l)[2], int key0, int q0, int lane, float c) {
@@ -113,7 +229,7 @@ __device__ __forceinline__ void fwd_tile(const char* ks, const char* vs, const b
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) kf[t][kk] = *reinterpret_cast<const bf16x8*>(ks + k_off(16 * t + li, 4 * kk + g));
-
+  const int rel0 = q0 + li - key0 - 4 * g;
   bf16x8 pf[2][2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
@@ -124,43 +240,7 @@ __device__ __forceinline__ void fwd_tile(const char* ks, const char* vs, const b
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[st][kk], s[t], 0, 0, 0);
     }
-    if (MASK) {
-      const int rel = q0 + 16 * st + li - key0 - 4 * g;  // key index 16t + e is allowed while 16t + e <= rel
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (16 * t + e > rel) s[t][e] = -__builtin_huge_valf();
-    }
-    // row maximum on the raw scores (the scale is positive), then one fused multiply-add per element
-    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
-#pragma unroll
-    for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m[st], mx * c);
-    const float alpha = fast_exp2(m[st] - m_new);
-    m[st] = m_new;
-    float ps = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pe = fast_exp2(fmaf(s[t][e], c, -m_new));
-        s[t][e] = pe;
-        ps += pe;
-      }
-    l[st] = fmaf(l[st], alpha, ps);  // per-lane partial sum; combined across the 4 lane groups at the end
-    if (__any(alpha != 1.f)) {        // the running maximum moved for some query of this wave
-#pragma unroll
-      for (int td = 0; td < 4; ++td)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[st][td][e] *= alpha;
-    }
-#pragma unroll
-    for (int sk = 0; sk < 2; ++sk)
-      pf[st][sk] = pack8(s[2 * sk][0], s[2 * sk][1], s[2 * sk][2], s[2 * sk][3], s[2 * sk + 1][0], s[2 * sk + 1][1],
-                         s[2 * sk + 1][2], s[2 * sk + 1][3]);
+    softmax_strip<MASK>(s, o[st], m[st], l[st], pf[st], rel0 + 16 * st, c);
   }
   // O^T += V^T P^T: V fragments are shared by both strips
 #pragma unroll
@@ -174,10 +254,12 @@ __device__ __forceinline__ void fwd_tile(const char* ks, const char* vs, const b
 }
 
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * kTileBytes];  // [2 stages][K | V]
+  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
   const int nqb = p.T / BQ;
-  const int qb = nqb - 1 - blockIdx.x;  // longest rows first
-  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  int blk, bh;
+  head_block_of_workgroup(nqb, blk, bh);
+  const int qb = nqb - 1 - blk;  // longest rows first
+  const int b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int q0 = qb * BQ + wid * 32;
@@ -195,6 +277,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
     for (int kk = 0; kk < 2; ++kk)
       qf[st][kk] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(q0 + 16 * st + li) * p.row_stride + 32 * kk + 8 * g);
 
+  wait_all_vmem();
+
   f32x4 o[2][4];
   float m[2], l[2];
 #pragma unroll
@@ -205,44 +289,50 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
     for (int td = 0; td < 4; ++td) o[st][td] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // K / V tiles travel global -> LDS by DMA through a ring of three stages: the tile two steps
+  // ahead is requested right after the barrier that publishes the current one, so every request
+  // has a whole tile of math to land behind.  Waves 0-1 move K pieces, waves 2-3 V pieces: four
+  // 1-KiB pieces per wave and tile.
   const int n_tiles = (qb * BQ + BQ) / BKV;
-  u32x4 rk[2], rv[2];
-  load_tile_regs(K, p.row_stride, 0, rk);
-  load_tile_regs(V, p.row_stride, 0, rv);
-  store_tile_regs<false>(smem, rk);
-  store_tile_regs<true>(smem + kTileBytes, rv);
-  __syncthreads();
-
-  for (int jt = 0; jt < n_tiles; ++jt) {
-    const int cur = jt & 1;
-    const bool more = jt + 1 < n_tiles;
-    if (more) {
-      load_tile_regs(K, p.row_stride, (jt + 1) * BKV, rk);
-      load_tile_regs(V, p.row_stride, (jt + 1) * BKV, rv);
+  const bool moves_v = wid >= 2;
+  const int piece0 = (wid & 1) * 4;
+  const u16* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    src[i] = moves_v ? dma_src<true>(V, p.row_stride, piece0 + i, lane) : dma_src<false>(K, p.row_stride, piece0 + i, lane);
+  const long long tile_step = static_cast<long long>(BKV) * p.row_stride;
+  const int dst0 = (moves_v ? kTileBytes : 0) + piece0 * 1024;
+  const unsigned smem_addr = lds_address(smem);
+  auto request = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma_16B(src[i], smem_addr + stage * 2 * kTileBytes + dst0 + i * 1024);
+      src[i] += tile_step;
     }
-    const char* ks = smem + cur * 2 * kTileBytes;
+  };
+  request(0);
+  if (n_tiles > 1) request(1);
+
+  int stage = 0;
+  for (int jt = 0; jt < n_tiles; ++jt) {
+    if (jt + 1 < n_tiles) wait_vmem_at_most<4>();  // this wave's pieces of tile jt have landed
+    else wait_vmem_at_most<0>();
+    __syncthreads();  // every wave's pieces are visible; nobody still reads the stage requested next
+    if (jt + 2 < n_tiles) request(stage == 0 ? 2 : stage - 1);
+    const char* ks = smem + stage * 2 * kTileBytes;
     const char* vs = ks + kTileBytes;
     const int key0 = jt * BKV;
-
     if (key0 <= q0 + 31) {  // otherwise every key of the tile is in this wave's future
       if (key0 + BKV - 1 > q0) fwd_tile<true>(ks, vs, qf, o, m, l, key0, q0, lane, p.scale_log2);
       else fwd_tile<false>(ks, vs, qf, o, m, l, key0, q0, lane, p.scale_log2);
     }
-
-    if (more) {
-      char* kn = smem + (cur ^ 1) * 2 * kTileBytes;
-      store_tile_regs<false>(kn, rk);
-      store_tile_regs<true>(kn + kTileBytes, rv);
-    }
-    __syncthreads();
+    stage = stage == 2 ? 0 : stage + 1;
   }
 
   // Normalise and store.  Lane: query li of strip st, d = 16*td + 4*g + e.
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    float lt = l[st];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    const float lt = groups_sum(l[st]);
     const float inv = 1.f / lt;
     const int qi = q0 + 16 * st + li;
     u16* orow = p.o + (static_cast<long long>(b) * p.T + qi) * (static_cast<long long>(p.H) * HD) + static_cast<long long>(h) * HD;
@@ -259,10 +349,11 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
 
 
 // =====================================================================================
-// Backward.  Three kernels, no atomics, no transposes through memory:
-//   attn_bwd_delta   delta[b,h,t] = sum_d dO * O
-//   attn_bwd_dq      same orientation as the forward (query on the lane): S^T = K Q^T and
-//                    dP^T = V dO^T share K / V row fragments, lse and delta are per-lane scalars,
+// Backward.  Two kernels, no atomics, no transposes through memory:
+//   attn_bwd_dq      first computes delta[b,h,t] = sum_d dO * O for its queries (and stores it for
+//                    the second kernel); same orientation as the forward (query on the lane):
+//                    S^T = K Q^T and dP^T = V dO^T share K / V row fragments, lse and delta are
+//                    per-lane scalars,
 //                    dS^T accumulators are the B operand of dQ^T[d][q] += K^T dS^T, whose A operand
 //                    is the transposing read of the same K tile.
 //   attn_bwd_dkdv    key on the lane: S = Q K^T and dP = dO V^T with the wave's K / V fragments
@@ -277,9 +368,11 @@ struct AttnBwdParams {
   const u16* q;
   const u16* k;
   const u16* v;
+  const u16* o;       // [B, T, H, 64]
   const u16* d_o;     // [B, T, H, 64]
   const float* lse;   // [B, H, T]
-  const float* delta; // [B, H, T]
+  float* delta;       // [B, H, T]: sum_d dO*O, written by the dQ kernel and read by the dK/dV kernel
+  float* lse2;        // [B, H, T]: lse * log2(e), likewise
   u16* dq;            // gradient tensors use grad_row_stride between consecutive t
   u16* dk;
   u16* dv;
@@ -287,27 +380,6 @@ struct AttnBwdParams {
   int B, H, T;
   float scale, scale_log2;
 };
-
-__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const u16* __restrict__ o, const u16* __restrict__ d_o,
-                                                             float* __restrict__ delta, int B, int H, int T) {
-  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;  // (b*T + t)*H + h
-  if (idx >= static_cast<long long>(B) * T * H) return;
-  const int h = static_cast<int>(idx % H);
-  const long long bt = idx / H;
-  const int t = static_cast<int>(bt % T), b = static_cast<int>(bt / T);
-  const u16* po = o + idx * HD;
-  const u16* pd = d_o + idx * HD;
-  float acc = 0.f;
-#pragma unroll
-  for (int i = 0; i < HD / 8; ++i) {
-    float a[8], c[8];
-    load_as_f32<BF16, 8>(po + 8 * i, a);
-    load_as_f32<BF16, 8>(pd + 8 * i, c);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc = fmaf(a[j], c[j], acc);
-  }
-  delta[(static_cast<long long>(b) * H + h) * T + t] = acc;
-}
 
 // Row fragment (A operand: row = tile row 16*t + li, k = 32*kk + 8*g ..) of a [rows][64] tile in the v_off image.
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int t, int kk, int lane) {
@@ -366,10 +438,12 @@ __device__ __forceinline__ void dq_tile(const char* ks, const char* vs, const bf
 }
 
 __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * kTileBytes];  // [2 stages][K | V]
+  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
   const int nqb = p.T / BQ;
-  const int qb = nqb - 1 - blockIdx.x;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  int blk, bh;
+  head_block_of_workgroup(nqb, blk, bh);
+  const int qb = nqb - 1 - blk;
+  const int b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int q0 = qb * BQ + wid * 32;
@@ -382,52 +456,69 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams 
   const u16* DO = p.d_o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
   const long long stat_off = (static_cast<long long>(b) * p.H + h) * p.T;
 
+  const u16* O = p.o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
   bf16x8 qf[2][2], dof[2][2];
   float lse2[2], dl[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
     const int qi = q0 + 16 * st + li;
+    float part = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       qf[st][kk] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(qi) * p.row_stride + 32 * kk + 8 * g);
       dof[st][kk] = *reinterpret_cast<const bf16x8*>(DO + static_cast<long long>(qi) * o_stride + 32 * kk + 8 * g);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + static_cast<long long>(qi) * o_stride + 32 * kk + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part = fmaf(static_cast<float>(dof[st][kk][j]), static_cast<float>(of[j]), part);
     }
     lse2[st] = p.lse[stat_off + qi] * 1.4426950408889634f;
-    dl[st] = p.delta[stat_off + qi];
+    // delta = sum_d dO*O of this query: the four lane groups hold 16 d each
+    dl[st] = groups_sum(part);
+    if (g == 0) {
+      p.delta[stat_off + qi] = dl[st];
+      p.lse2[stat_off + qi] = lse2[st];
+    }
   }
+  wait_all_vmem();
   f32x4 dq[2][4];
 #pragma unroll
   for (int st = 0; st < 2; ++st)
 #pragma unroll
     for (int td = 0; td < 4; ++td) dq[st][td] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Same three-stage LDS-DMA ring as the forward kernel; both tiles use the v_off image here
+  // because K is read row-wise (S^T) and transposed (dQ^T) from the same copy.
   const int n_tiles = (qb * BQ + BQ) / BKV;
-  u32x4 rk[2], rv[2];
-  load_tile_regs(K, p.row_stride, 0, rk);
-  load_tile_regs(V, p.row_stride, 0, rv);
-  store_tile_regs<true>(smem, rk);
-  store_tile_regs<true>(smem + kTileBytes, rv);
-  __syncthreads();
-  for (int jt = 0; jt < n_tiles; ++jt) {
-    const int cur = jt & 1;
-    const bool more = jt + 1 < n_tiles;
-    if (more) {
-      load_tile_regs(K, p.row_stride, (jt + 1) * BKV, rk);
-      load_tile_regs(V, p.row_stride, (jt + 1) * BKV, rv);
+  const bool moves_v = wid >= 2;
+  const int piece0 = (wid & 1) * 4;
+  const u16* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) src[i] = dma_src<true>(moves_v ? V : K, p.row_stride, piece0 + i, lane);
+  const long long tile_step = static_cast<long long>(BKV) * p.row_stride;
+  const unsigned dst0 = lds_address(smem) + (moves_v ? kTileBytes : 0) + piece0 * 1024;
+  auto request = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma_16B(src[i], dst0 + stage * 2 * kTileBytes + i * 1024);
+      src[i] += tile_step;
     }
-    const char* ks = smem + cur * 2 * kTileBytes;
+  };
+  request(0);
+  if (n_tiles > 1) request(1);
+  int stage = 0;
+  for (int jt = 0; jt < n_tiles; ++jt) {
+    if (jt + 1 < n_tiles) wait_vmem_at_most<4>();
+    else wait_vmem_at_most<0>();
+    __syncthreads();
+    if (jt + 2 < n_tiles) request(stage == 0 ? 2 : stage - 1);
+    const char* ks = smem + stage * 2 * kTileBytes;
     const char* vs = ks + kTileBytes;
     const int key0 = jt * BKV;
     if (key0 <= q0 + 31) {
       if (key0 + BKV - 1 > q0) dq_tile<true>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2, p.scale);
       else dq_tile<false>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2, p.scale);
     }
-    if (more) {
-      char* kn = smem + (cur ^ 1) * 2 * kTileBytes;
-      store_tile_regs<true>(kn, rk);
-      store_tile_regs<true>(kn + kTileBytes, rv);
-    }
-    __syncthreads();
+    stage = stage == 2 ? 0 : stage + 1;
   }
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
@@ -443,37 +534,36 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams 
   }
 }
 
-constexpr int BQT = 32;                          // queries per tile in the dK/dV kernel
-constexpr int kQTileBytes = BQT * HD * 2;        // 4 KiB
+constexpr int BQT = 64;                          // queries per LDS stage in the dK/dV kernel (two 32-query halves)
+constexpr int kQTileBytes = BQT * HD * 2;        // 8 KiB
+constexpr int kQStageBytes = 2 * kQTileBytes + 2 * BQT * 4;  // Q | dO | lse*log2(e) | delta
 
-__device__ __forceinline__ void load_qtile_regs(const u16* base, long long row_stride, int row0, u32x4& r) {
-  const int id = threadIdx.x;  // 256 pieces of 16 B: 32 rows x 8 chunks
-  r = *reinterpret_cast<const u32x4*>(base + static_cast<long long>(row0 + (id >> 3)) * row_stride + ((id & 7) << 3));
-}
-__device__ __forceinline__ void store_qtile_regs(char* tile, const u32x4& r) {
-  const int id = threadIdx.x;
-  *reinterpret_cast<u32x4*>(tile + v_off(id >> 3, id & 7)) = r;
+// 64 consecutive floats -> 256 bytes of LDS, one per lane.
+__device__ __forceinline__ void dma_4B(const float* src, unsigned lds_addr) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(a) : "memory");
 }
 
 template <bool MASK>
 __device__ __forceinline__ void dkdv_tile(const char* qs_, const char* dos_, const bf16x8 (&kfB)[2][2], const bf16x8 (&vfB)[2][2],
-                                          f32x4 (&dk)[2][4], f32x4 (&dv)[2][4], const float* lse, const float* delta, int qt0,
+                                          f32x4 (&dk)[2][4], f32x4 (&dv)[2][4], const char* stats, int hf, int qt0,
                                           int k0w, int lane, float c, float scale) {
+  // Works on the 32 queries qt0 .. qt0+31, which are rows 32*hf .. 32*hf+31 of the stage's tiles.
   const int g = lane >> 4, li = lane & 15;
   // per-register query statistics: query = qt0 + 16*qs + 4*g + e
   f32x4 l2[2], dl[2];
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
-    l2[qs] = *reinterpret_cast<const f32x4*>(lse + qt0 + 16 * qs + 4 * g);
-    dl[qs] = *reinterpret_cast<const f32x4*>(delta + qt0 + 16 * qs + 4 * g);
+    l2[qs] = *reinterpret_cast<const f32x4*>(stats + (32 * hf + 16 * qs + 4 * g) * 4);
+    dl[qs] = *reinterpret_cast<const f32x4*>(stats + BQT * 4 + (32 * hf + 16 * qs + 4 * g) * 4);
   }
   bf16x8 qrow[2][2], dorow[2][2];
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      qrow[qs][kk] = row_frag(qs_, qs, kk, lane);
-      dorow[qs][kk] = row_frag(dos_, qs, kk, lane);
+      qrow[qs][kk] = row_frag(qs_, 2 * hf + qs, kk, lane);
+      dorow[qs][kk] = row_frag(dos_, 2 * hf + qs, kk, lane);
     }
   bf16x8 pB[2], dsB[2];
 #pragma unroll
@@ -496,7 +586,7 @@ __device__ __forceinline__ void dkdv_tile(const char* qs_, const char* dos_, con
     for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float pe = fast_exp2(fmaf(s[qs][e], c, -l2[qs][e] * 1.4426950408889634f));
+        float pe = fast_exp2(fmaf(s[qs][e], c, -l2[qs][e]));
         if (MASK && (16 * qs + e < rel)) pe = 0.f;
         pv[qs][e] = pe;
         dsv[qs][e] = pe * (dp[qs][e] - dl[qs][e]) * scale;
@@ -507,8 +597,8 @@ __device__ __forceinline__ void dkdv_tile(const char* qs_, const char* dos_, con
   // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS   (contraction over the tile's 32 queries)
 #pragma unroll
   for (int td = 0; td < 4; ++td) {
-    const bf16x8 dot = tr_frag(dos_, 0, td, lane);
-    const bf16x8 qt = tr_frag(qs_, 0, td, lane);
+    const bf16x8 dot = tr_frag(dos_, 32 * hf, td, lane);
+    const bf16x8 qt = tr_frag(qs_, 32 * hf, td, lane);
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
       dv[kt2][td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pB[kt2], dv[kt2][td], 0, 0, 0);
@@ -518,9 +608,10 @@ __device__ __forceinline__ void dkdv_tile(const char* qs_, const char* dos_, con
 }
 
 __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * kQTileBytes];  // [2 stages][Q | dO]
-  const int jb = blockIdx.x;  // key block; block 0 has the most query tiles and starts first
-  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  __shared__ __attribute__((aligned(1024))) char smem[3 * kQStageBytes];  // [3 stages][Q | dO | lse2 | delta]
+  int jb, bh;  // key block; block 0 has the most query tiles and starts first
+  head_block_of_workgroup(p.T / BQ, jb, bh);
+  const int b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int k0w = jb * BQ + wid * 32;  // this wave's 32 keys
@@ -532,7 +623,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParam
   const long long o_stride = static_cast<long long>(p.H) * HD;
   const u16* DO = p.d_o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
   const long long stat_off = (static_cast<long long>(b) * p.H + h) * p.T;
-  const float* lse = p.lse + stat_off;
+  const float* lse2 = p.lse2 + stat_off;
   const float* delta = p.delta + stat_off;
 
   // K / V fragments as B operands (col = key li of key tile kt2, k = d), resident for the whole kernel
@@ -545,6 +636,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParam
       kfB[kt2][kk] = *reinterpret_cast<const bf16x8*>(K + row * p.row_stride + 32 * kk + 8 * g);
       vfB[kt2][kk] = *reinterpret_cast<const bf16x8*>(V + row * p.row_stride + 32 * kk + 8 * g);
     }
+  wait_all_vmem();
   f32x4 dk[2][4], dv[2][4];
 #pragma unroll
   for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -554,33 +646,58 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParam
       dv[kt2][td] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+  // Q / dO tiles (64 queries) and the queries' statistics arrive by LDS-DMA through a three-stage
+  // ring, as in the other kernels: waves 0-1 move Q pieces, waves 2-3 dO pieces, wave 0 also the 64
+  // log-sum-exp values and wave 2 the 64 delta values (one 4-byte DMA each).
   const int first_qt = (jb * BQ) / BQT, n_qt = p.T / BQT;
-  u32x4 rq, rdo;
-  load_qtile_regs(Q, p.row_stride, first_qt * BQT, rq);
-  load_qtile_regs(DO, o_stride, first_qt * BQT, rdo);
-  store_qtile_regs(smem, rq);
-  store_qtile_regs(smem + kQTileBytes, rdo);
-  __syncthreads();
-  for (int qt = first_qt; qt < n_qt; ++qt) {
-    const int cur = (qt - first_qt) & 1;
-    const bool more = qt + 1 < n_qt;
-    if (more) {
-      load_qtile_regs(Q, p.row_stride, (qt + 1) * BQT, rq);
-      load_qtile_regs(DO, o_stride, (qt + 1) * BQT, rdo);
+  const bool moves_do = wid >= 2, moves_stat = (wid & 1) == 0;
+  const int piece0 = (wid & 1) * 4;
+  const long long src_stride = moves_do ? o_stride : p.row_stride;
+  const u16* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    src[i] = dma_src<true>((moves_do ? DO : Q) + static_cast<long long>(first_qt) * BQT * src_stride, src_stride, piece0 + i, lane);
+  const float* stat_src = (moves_do ? delta : lse2) + first_qt * BQT + lane;
+  const long long tile_step = static_cast<long long>(BQT) * src_stride;
+  const unsigned smem_addr = lds_address(smem);
+  const unsigned dst0 = smem_addr + (moves_do ? kQTileBytes : 0) + piece0 * 1024;
+  const unsigned stat_dst0 = smem_addr + 2 * kQTileBytes + (moves_do ? BQT * 4 : 0);
+  auto request = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma_16B(src[i], dst0 + stage * kQStageBytes + i * 1024);
+      src[i] += tile_step;
     }
-    const char* qs_ = smem + cur * 2 * kQTileBytes;
-    const char* dos_ = qs_ + kQTileBytes;
-    const int qt0 = qt * BQT;
-    if (qt0 + BQT - 1 >= k0w) {  // otherwise every query of the tile precedes all of this wave's keys
-      if (qt0 < k0w + 31) dkdv_tile<true>(qs_, dos_, kfB, vfB, dk, dv, lse, delta, qt0, k0w, lane, p.scale_log2, p.scale);
-      else dkdv_tile<false>(qs_, dos_, kfB, vfB, dk, dv, lse, delta, qt0, k0w, lane, p.scale_log2, p.scale);
+    if (moves_stat) {
+      dma_4B(stat_src, stat_dst0 + stage * kQStageBytes);
+      stat_src += BQT;
     }
-    if (more) {
-      char* qn = smem + (cur ^ 1) * 2 * kQTileBytes;
-      store_qtile_regs(qn, rq);
-      store_qtile_regs(qn + kQTileBytes, rdo);
+  };
+  const int n_iter = n_qt - first_qt;
+  request(0);
+  if (n_iter > 1) request(1);
+  int stage = 0;
+  for (int it = 0; it < n_iter; ++it) {
+    if (it + 1 < n_iter) {  // leave the next stage's requests in flight: 5 per wave with statistics, else 4
+      if (moves_stat) wait_vmem_at_most<5>();
+      else wait_vmem_at_most<4>();
+    } else {
+      wait_vmem_at_most<0>();
     }
     __syncthreads();
+    if (it + 2 < n_iter) request(stage == 0 ? 2 : stage - 1);
+    const char* qs_ = smem + stage * kQStageBytes;
+    const char* dos_ = qs_ + kQTileBytes;
+    const char* stats = qs_ + 2 * kQTileBytes;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int qt0 = (first_qt + it) * BQT + 32 * hf;
+      if (qt0 + 31 >= k0w) {  // otherwise every query of the half precedes all of this wave's keys
+        if (qt0 < k0w + 31) dkdv_tile<true>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2, p.scale);
+        else dkdv_tile<false>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2, p.scale);
+      }
+    }
+    stage = stage == 2 ? 0 : stage + 1;
   }
   // lane: key = k0w + 16*kt2 + li, d = 16*td + 4*g + e
 #pragma unroll
@@ -617,22 +734,21 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
   p.row_stride = row_stride;
   p.B = B; p.H = H; p.T = T;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(T / BQ, B * H), dim3(kThreads), 0, stream, p);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(static_cast<unsigned>(T / BQ) * static_cast<unsigned>(B * H)), dim3(kThreads), 0, stream, p);
 }
 
 void launch_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, long long row_stride, long long grad_row_stride, int B, int H, int T,
                           float softmax_scale, hipStream_t stream) {
-  const long long n = static_cast<long long>(B) * T * H;
-  hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<const u16*>(o), static_cast<const u16*>(d_o), delta, B, H, T);
   AttnBwdParams p;
+  p.o = static_cast<const u16*>(o);
   p.q = static_cast<const u16*>(q);
   p.k = static_cast<const u16*>(k);
   p.v = static_cast<const u16*>(v);
   p.d_o = static_cast<const u16*>(d_o);
   p.lse = lse;
-  p.delta = delta;
+  p.delta = delta;  // workspace of 2*B*H*T floats: delta, then lse in the log2 domain
+  p.lse2 = delta + static_cast<long long>(B) * H * T;
   p.dq = static_cast<u16*>(dq);
   p.dk = static_cast<u16*>(dk);
   p.dv = static_cast<u16*>(dv);
@@ -641,8 +757,9 @@ void launch_attention_bwd(const void* q, const void* k, const void* v, const voi
   p.B = B; p.H = H; p.T = T;
   p.scale = softmax_scale;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(T / BQ, B * H), dim3(kThreads), 0, stream, p);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(T / BQ, B * H), dim3(kThreads), 0, stream, p);
+  // dQ first: it also produces delta, which the dK/dV kernel consumes
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(static_cast<unsigned>(T / BQ) * static_cast<unsigned>(B * H)), dim3(kThreads), 0, stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(static_cast<unsigned>(T / BQ) * static_cast<unsigned>(B * H)), dim3(kThreads), 0, stream, p);
 }
 
 }  // namespace kernels

@@ -149,7 +149,7 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, cons
 // ------------------------------------------------------------------ causal attention (head dim 64, bf16)
 // q/k/v element (b, t, h, d) lives at ptr[(b*T + t) * row_stride + h*64 + d] (a packed
 // [B, T, 3, H, 64] projection has row_stride = 3*H*64 and k = q + H*64, v = q + 2*H*64).
-// o / do are [B, T, H, 64] contiguous; lse and delta are [B, H, T] fp32.
+// o / do are [B, T, H, 64] contiguous; lse is [B, H, T] fp32; delta is a workspace of 2*B*H*T floats.
 bool attention_supported(long long T, long long head_dim, long long row_stride);
 void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                           long long row_stride, int B, int H, int T, float softmax_scale,

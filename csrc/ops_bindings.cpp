@@ -506,7 +506,7 @@ Tensor attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t 
   TORCH_CHECK(lse.scalar_type() == at::kFloat && lse.numel() == B * n_head * T, "attention_backward: lse must be float32 [B, H, T]");
   TORCH_CHECK(kernels::attention_supported(T, hd, C3), "attention_backward: unsupported shape");
   Tensor dqkv = at::empty_like(qkv);
-  Tensor delta = at::empty({B, n_head, T}, lse.options());
+  Tensor delta = at::empty({2, B, n_head, T}, lse.options());  // delta | lse*log2(e), filled by the dQ kernel
   DevGuard guard(qkv);
   const char* base = static_cast<const char*>(qkv.data_ptr());
   char* gbase = static_cast<char*>(dqkv.data_ptr());

@@ -31,10 +31,21 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x).  Phi comes from the Abramowitz-Stegun 7.1.26 rational
+// form of erf (absolute error 1.5e-7, fp32-level), which needs exp(-x^2/2) -- the same exponential
+// the density term uses -- so the whole derivative costs one v_exp, one v_rcp and eight FMAs
+// instead of a libm erff call (the backward of the GELU layers is VALU-bound otherwise).
 __device__ __forceinline__ float gelu_grad(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float ax = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);  // exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.f));       // 1 / (1 + p*|x|/sqrt(2)), p = 0.3275911
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float tail = 0.5f * poly * t * e;            // 1 - Phi(|x|)
+  const float cdf = x >= 0.f ? 1.f - tail : tail;
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // ------------------------------------------------------------------ K = 1 forward
@@ -256,6 +267,11 @@ enum ColMode : int { kColSum = 0, kOuterWgrad = 1, kActBwd = 2 };
 //   kColSum     : partial_b[chunk][n] = sum_m dy[m][n]
 //   kOuterWgrad : also partial_w[chunk][n] = sum_m dy[m][n] * xrow[m]
 //   kActBwd     : g[m][n] = dy[m][n] * act'(saved[m][n]) is written, partial_b sums g
+// A workgroup is 8 row lanes x 32 column lanes; a column lane owns one 16-byte vector, so a
+// column tile is 512 bytes of a row (fully used cache lines) and even a 768-column matrix keeps
+// every lane busy.  Each thread walks rows m0 + r, m0 + r + 8, ...; LDS folds the 8 row lanes.
+constexpr int kColLanes = 32, kRowLanes = 8;
+
 template <typename TR, int MODE>
 __global__ __launch_bounds__(kThreads) void col_reduce_partial_kernel(const typename TR::T* __restrict__ dy,
                                                                       const typename TR::T* __restrict__ aux,
@@ -264,8 +280,10 @@ __global__ __launch_bounds__(kThreads) void col_reduce_partial_kernel(const type
                                                                       float* __restrict__ partial_w, long long M,
                                                                       long long N, int rows_per_chunk, int act) {
   constexpr int V = TR::kVec;
-  const long long n0 = (static_cast<long long>(blockIdx.x) * kThreads + threadIdx.x) * V;
-  if (n0 >= N) return;
+  constexpr int TILE = kColLanes * V;
+  __shared__ float red[kRowLanes][TILE + 1];
+  const int cl = threadIdx.x & (kColLanes - 1), rl = threadIdx.x / kColLanes;
+  const long long n0 = (static_cast<long long>(blockIdx.x) * kColLanes + cl) * V;
   const long long m0 = static_cast<long long>(blockIdx.y) * rows_per_chunk;
   const long long m1 = m0 + rows_per_chunk < M ? m0 + rows_per_chunk : M;
   uintptr_t bits = reinterpret_cast<uintptr_t>(dy);
@@ -274,42 +292,62 @@ __global__ __launch_bounds__(kThreads) void col_reduce_partial_kernel(const type
   float sb[V], sw[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) sb[j] = sw[j] = 0.f;
-  for (long long m = m0; m < m1; ++m) {
-    float d[V];
-    if (vec) load_as_f32<TR, V>(dy + m * N + n0, d);
-    else {
-#pragma unroll
-      for (int j = 0; j < V; ++j) d[j] = (n0 + j < N) ? TR::to_f32(dy[m * N + n0 + j]) : 0.f;
-    }
-    if (MODE == kActBwd) {
-      float s[V];
-      if (vec) load_as_f32<TR, V>(aux + m * N + n0, s);
+  if (n0 < N) {
+#pragma unroll 4
+    for (long long m = m0 + rl; m < m1; m += kRowLanes) {
+      float d[V];
+      if (vec) load_as_f32<TR, V>(dy + m * N + n0, d);
       else {
 #pragma unroll
-        for (int j = 0; j < V; ++j) s[j] = (n0 + j < N) ? TR::to_f32(aux[m * N + n0 + j]) : 0.f;
+        for (int j = 0; j < V; ++j) d[j] = (n0 + j < N) ? TR::to_f32(dy[m * N + n0 + j]) : 0.f;
+      }
+      if (MODE == kActBwd) {
+        float sv[V];
+        if (vec) load_as_f32<TR, V>(aux + m * N + n0, sv);
+        else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) sv[j] = (n0 + j < N) ? TR::to_f32(aux[m * N + n0 + j]) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          if (act == kActRelu) d[j] = sv[j] > 0.f ? d[j] : 0.f;
+          else if (act == kActGelu) d[j] *= gelu_grad(sv[j]);
+        }
+        if (vec) store_from_f32<TR, V>(g_out + m * N + n0, d);
+        else
+          for (int j = 0; j < V && n0 + j < N; ++j) g_out[m * N + n0 + j] = TR::from_f32(d[j]);
+      }
+      if (MODE == kOuterWgrad) {
+        const float xv = TR::to_f32(aux[m]);
+#pragma unroll
+        for (int j = 0; j < V; ++j) sw[j] = fmaf(d[j], xv, sw[j]);
       }
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        if (act == kActRelu) d[j] = s[j] > 0.f ? d[j] : 0.f;
-        else if (act == kActGelu) d[j] *= gelu_grad(s[j]);
-      }
-      if (vec) store_from_f32<TR, V>(g_out + m * N + n0, d);
-      else
-        for (int j = 0; j < V && n0 + j < N; ++j) g_out[m * N + n0 + j] = TR::from_f32(d[j]);
+      for (int j = 0; j < V; ++j) sb[j] += d[j];
     }
-    if (MODE == kOuterWgrad) {
-      const float xv = TR::to_f32(aux[m]);
-#pragma unroll
-      for (int j = 0; j < V; ++j) sw[j] = fmaf(d[j], xv, sw[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < V; ++j) sb[j] += d[j];
   }
-  float* ob = partial_b + static_cast<long long>(blockIdx.y) * N;
-  for (int j = 0; j < V && n0 + j < N; ++j) ob[n0 + j] = sb[j];
+  // fold the 8 row lanes: thread t then owns column t of the tile
+  const long long nt = static_cast<long long>(blockIdx.x) * TILE + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[rl][cl * V + j] = sb[j];
+  __syncthreads();
+  if (threadIdx.x < TILE && nt < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < kRowLanes; ++r) t += red[r][threadIdx.x];
+    partial_b[static_cast<long long>(blockIdx.y) * N + nt] = t;
+  }
   if (MODE == kOuterWgrad) {
-    float* ow = partial_w + static_cast<long long>(blockIdx.y) * N;
-    for (int j = 0; j < V && n0 + j < N; ++j) ow[n0 + j] = sw[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[rl][cl * V + j] = sw[j];
+    __syncthreads();
+    if (threadIdx.x < TILE && nt < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < kRowLanes; ++r) t += red[r][threadIdx.x];
+      partial_w[static_cast<long long>(blockIdx.y) * N + nt] = t;
+    }
   }
 }
 
@@ -351,7 +389,7 @@ void col_reduce(const void* dy, const void* aux, void* g, void* db, void* dw, fl
   using T = typename TR::T;
   const int rpc = pick_rows_per_chunk(M, kMaxChunks);
   const int chunks = static_cast<int>((M + rpc - 1) / rpc);
-  const int col_tiles = static_cast<int>((N + kThreads * TR::kVec - 1) / (kThreads * TR::kVec));
+  const int col_tiles = static_cast<int>((N + kColLanes * TR::kVec - 1) / (kColLanes * TR::kVec));
   float* pb = workspace;
   float* pw = workspace + static_cast<long long>(chunks) * N;
   if (MODE == kColSum && N <= 16) {

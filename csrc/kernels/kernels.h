@@ -138,13 +138,16 @@ void launch_act_bwd(const void* dy, const void* saved, void* g, void* db, float*
                     long long M, long long N, int dtype, int act, hipStream_t stream);
 
 // ------------------------------------------------------------------ layer norm
-void launch_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean,
-                          float* rstd, long long rows, long long cols, float eps, int dtype,
-                          hipStream_t stream);
+// With `res` != nullptr: s = x + res is written to `sum_out` and y = LN(s); else y = LN(x).
+void launch_layernorm_fwd(const void* x, const void* res, void* sum_out, const void* gamma,
+                          const void* beta, void* y, float* mean, float* rstd, long long rows,
+                          long long cols, float eps, int dtype, hipStream_t stream);
 long long layernorm_bwd_workspace(long long rows, long long cols);
-void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean,
-                          const float* rstd, void* dx, void* dgamma, void* dbeta, float* workspace,
-                          long long rows, long long cols, int dtype, hipStream_t stream);
+// dx = LN'(dy) (+ dres when given: the gradient reaching the normalised tensor by another path).
+void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const void* gamma,
+                          const float* mean, const float* rstd, void* dx, void* dgamma, void* dbeta,
+                          float* workspace, long long rows, long long cols, int dtype,
+                          hipStream_t stream);
 
 // ------------------------------------------------------------------ causal attention (head dim 64, bf16)
 // q/k/v element (b, t, h, d) lives at ptr[(b*T + t) * row_stride + h*64 + d] (a packed

@@ -2,7 +2,11 @@
 //
 // One 64-lane wave owns one row and keeps it in registers: the row is read from HBM once,
 // mean and variance are two wave-shuffle reductions, and the result is written once
-// (16-byte accesses per lane).  The backward pass does the same per row for dx, and because
+// (16-byte accesses per lane).  The residual add in front of a transformer's layer norm is folded
+// in: with `res` the kernel normalises s = x + res and also writes s (rounded to the storage type
+// first, so the result equals the unfused add followed by layer norm), and the backward adds the
+// gradient arriving at s from the residual path (`dres`) to the layer-norm gradient -- the separate
+// elementwise add passes disappear in both directions.  The backward pass does the same per row for dx, and because
 // a lane always owns the same columns it accumulates its share of dgamma / dbeta in
 // registers across all rows its workgroup visits; workgroups then emit one partial row
 // each and a second small kernel sums them (deterministic, no float atomics).
@@ -18,11 +22,13 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxBlocks = 512;
+constexpr int kMaxBlocks = 2048;
 
 // MAXV = vectors (of TR::kVec elements) per lane; supports cols <= 64 * kVec * MAXV.
 template <typename TR, int MAXV>
 __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename TR::T* __restrict__ x,
+                                                                 const typename TR::T* __restrict__ res,
+                                                                 typename TR::T* __restrict__ sum_out,
                                                                  const typename TR::T* __restrict__ gamma,
                                                                  const typename TR::T* __restrict__ beta,
                                                                  typename TR::T* __restrict__ y, float* __restrict__ mean_out,
@@ -41,6 +47,13 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
       const int vi = lane + 64 * i;
       if (vi < nvec) {
         load_as_f32<TR, V>(xr + vi * V, v[i]);
+        if (res) {
+          float r[V];
+          load_as_f32<TR, V>(res + row * cols + vi * V, r);
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[i][j] = TR::to_f32(TR::from_f32(v[i][j] + r[j]));
+          store_from_f32<TR, V>(sum_out + row * cols + vi * V, v[i]);
+        }
 #pragma unroll
         for (int j = 0; j < V; ++j) s += v[i][j];
       }
@@ -81,6 +94,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
 template <typename TR, int MAXV>
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename TR::T* __restrict__ dy,
                                                                  const typename TR::T* __restrict__ x,
+                                                                 const typename TR::T* __restrict__ dres,
                                                                  const typename TR::T* __restrict__ gamma,
                                                                  const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                                  typename TR::T* __restrict__ dx, float* __restrict__ partial,
@@ -130,6 +144,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
         float o[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = rstd * (gy[i][j] - s1 - xh[i][j] * s2);
+        if (dres) {
+          float r[V];
+          load_as_f32<TR, V>(dres + row * cols + vi * V, r);
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] += r[j];
+        }
         store_from_f32<TR, V>(dx + row * cols + vi * V, o);
       }
     }
@@ -200,8 +220,8 @@ bool dispatch_maxv(int need, int limit, F&& f) {
 
 }  // namespace
 
-void launch_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, long long rows,
-                          long long cols, float eps, int dtype, hipStream_t stream) {
+void launch_layernorm_fwd(const void* x, const void* res, void* sum_out, const void* gamma, const void* beta, void* y, float* mean,
+                          float* rstd, long long rows, long long cols, float eps, int dtype, hipStream_t stream) {
   if (rows <= 0) return;
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
@@ -212,16 +232,16 @@ void launch_layernorm_fwd(const void* x, const void* gamma, const void* beta, vo
     dispatch_maxv(need, 8, [&](auto mv) {
       constexpr int MAXV = decltype(mv)::value;
       hipLaunchKernelGGL((layernorm_fwd_kernel<TR, MAXV>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream,
-                         static_cast<const T*>(x), static_cast<const T*>(gamma), static_cast<const T*>(beta), static_cast<T*>(y), mean,
-                         rstd, rows, static_cast<int>(cols), eps);
+                         static_cast<const T*>(x), static_cast<const T*>(res), static_cast<T*>(sum_out), static_cast<const T*>(gamma),
+                         static_cast<const T*>(beta), static_cast<T*>(y), mean, rstd, rows, static_cast<int>(cols), eps);
     });
   });
 }
 
 long long layernorm_bwd_workspace(long long rows, long long cols) { return 2 * cols * pick_blocks(rows); }
 
-void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, void* dx, void* dgamma,
-                          void* dbeta, float* workspace, long long rows, long long cols, int dtype, hipStream_t stream) {
+void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const void* gamma, const float* mean, const float* rstd, void* dx,
+                          void* dgamma, void* dbeta, float* workspace, long long rows, long long cols, int dtype, hipStream_t stream) {
   if (rows <= 0) return;
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
@@ -232,8 +252,8 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* gamma, cons
     dispatch_maxv(need, 4, [&](auto mv) {
       constexpr int MAXV = decltype(mv)::value;
       hipLaunchKernelGGL((layernorm_bwd_kernel<TR, (MAXV > 4 ? 4 : MAXV)>), dim3(blocks), dim3(kThreads), lds, stream,
-                         static_cast<const T*>(dy), static_cast<const T*>(x), static_cast<const T*>(gamma), mean, rstd, static_cast<T*>(dx),
-                         workspace, rows, static_cast<int>(cols));
+                         static_cast<const T*>(dy), static_cast<const T*>(x), static_cast<const T*>(dres), static_cast<const T*>(gamma), mean,
+                         rstd, static_cast<T*>(dx), workspace, rows, static_cast<int>(cols));
     });
     hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((2 * cols + 31) / 32)), dim3(kThreads),
                        0, stream, workspace, static_cast<T*>(dgamma), static_cast<T*>(dbeta), static_cast<int>(cols), blocks);

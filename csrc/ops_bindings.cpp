@@ -432,7 +432,8 @@ Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tens
 }
 
 // ------------------------------------------------------------------ layer norm
-std::tuple<Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor gamma, Tensor beta, double eps) {
+// y = LN(x) or, with `res`, s = x + res and y = LN(s).  Returns (y, mean, rstd, s); s is x itself without `res`.
+std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor gamma, Tensor beta, double eps, c10::optional<Tensor> res) {
   check_gpu(x, "x");
   check_gpu(gamma, "weight");
   check_gpu(beta, "bias");
@@ -445,15 +446,25 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor gamma, Ten
     TORCH_CHECK(cols % vec == 0 && cols <= 64 * vec * 8, "layernorm_forward: cols must be a multiple of ", vec, " and at most ", 64 * vec * 8);
   }
   Tensor y = at::empty_like(x);
+  Tensor sum = x;
+  const void* res_ptr = nullptr;
+  if (res.has_value()) {
+    check_gpu(*res, "res");
+    TORCH_CHECK(res->sizes() == x.sizes() && res->scalar_type() == x.scalar_type() && res->get_device() == x.get_device(),
+                "layernorm_forward: res must match x");
+    sum = at::empty_like(x);
+    res_ptr = res->data_ptr();
+  }
   auto fopt = x.options().dtype(at::kFloat);
   Tensor mean = at::empty({rows}, fopt), rstd = at::empty({rows}, fopt);
   DevGuard guard(x);
-  kernels::launch_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
-                                rows, cols, static_cast<float>(eps), kdtype(x), stream_of(x));
-  return {y, mean, rstd};
+  kernels::launch_layernorm_fwd(x.data_ptr(), res_ptr, res_ptr ? sum.data_ptr() : nullptr, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                mean.data_ptr<float>(), rstd.data_ptr<float>(), rows, cols, static_cast<float>(eps), kdtype(x), stream_of(x));
+  return {y, mean, rstd, sum};
 }
 
-std::tuple<Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tensor gamma, Tensor mean, Tensor rstd) {
+// dx = LN'(dy) + dres (dres optional).
+std::tuple<Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tensor gamma, Tensor mean, Tensor rstd, c10::optional<Tensor> dres) {
   check_gpu(dy, "dy");
   check_gpu(x, "x");
   check_gpu(gamma, "weight");
@@ -467,11 +478,18 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tenso
     const int64_t vec = 16 / x.element_size();
     TORCH_CHECK(cols % vec == 0 && cols <= 64 * vec * 4, "layernorm_backward: cols must be a multiple of ", vec, " and at most ", 64 * vec * 4);
   }
+  const void* dres_ptr = nullptr;
+  if (dres.has_value()) {
+    check_gpu(*dres, "dres");
+    TORCH_CHECK(dres->sizes() == x.sizes() && dres->scalar_type() == x.scalar_type() && dres->get_device() == x.get_device(),
+                "layernorm_backward: dres must match x");
+    dres_ptr = dres->data_ptr();
+  }
   Tensor dx = at::empty_like(x), dgamma = at::empty_like(gamma), dbeta = at::empty_like(gamma);
   Tensor ws = at::empty({kernels::layernorm_bwd_workspace(rows, cols)}, x.options().dtype(at::kFloat));
   DevGuard guard(x);
-  kernels::launch_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(), dx.data_ptr(),
-                                dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr<float>(), rows, cols, kdtype(x), stream_of(x));
+  kernels::launch_layernorm_bwd(dy.data_ptr(), x.data_ptr(), dres_ptr, gamma.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
+                                dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr<float>(), rows, cols, kdtype(x), stream_of(x));
   return {dx, dgamma, dbeta};
 }
 
@@ -549,8 +567,10 @@ void init_ops(py::module_& m) {
   m.def("colsum", &colsum);
   m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),
         py::arg("act") = 0);
-  m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5);
-  m.def("layernorm_backward", &layernorm_backward);
+  m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5,
+        py::arg("res") = py::none());
+  m.def("layernorm_backward", &layernorm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"), py::arg("rstd"),
+        py::arg("dres") = py::none());
   m.attr("ACT_NONE") = static_cast<int>(kernels::kActNone);
   m.attr("ACT_RELU") = static_cast<int>(kernels::kActRelu);
   m.attr("ACT_GELU") = static_cast<int>(kernels::kActGelu);

@@ -14,7 +14,7 @@ import torch
 
 from .. import _ext
 
-GPT2_TOKENS = 32768
+GPT2_TOKENS = 65536
 SHAPES = [
     # (name, M, N, K, a_kmajor, b_kmajor)
     ("sq4096 NT", 4096, 4096, 4096, True, True),

@@ -44,6 +44,7 @@ class GPT2Config:
     inplace_loss_backward: bool = True
     native_ops: bool = True       # False: stock torch layer norm / GELU / cross-entropy (comparison baseline)
     attention_impl: str = "auto"  # auto | native | sdpa
+    fuse_add_norm: bool = True    # fold each residual add into the layer norm that follows it
 
     @property
     def padded_vocab_size(self) -> int:
@@ -119,6 +120,15 @@ class Block(nn.Module):
         x = x + self.mlp(self.ln_2(x))
         return x
 
+    def forward_deferred(self, x, pending):
+        """Same block with every residual add folded into the layer norm that follows it: takes the
+        residual stream ``x`` plus the not-yet-added output ``pending`` of the previous branch and
+        returns the new stream and this block's own pending MLP output."""
+        x, h = self.ln_1.forward_add(x, pending)
+        a = self.attn(h)
+        x, h = self.ln_2.forward_add(x, a)
+        return x, self.mlp(h)
+
 
 class GPT2(nn.Module):
     def __init__(self, cfg: GPT2Config):
@@ -160,9 +170,15 @@ class GPT2(nn.Module):
         assert T <= self.cfg.block_size
         pos = torch.arange(T, device=idx.device)
         x = self.wte(idx) + self.wpe(pos)
-        for blk in self.h:
-            x = blk(x)
-        x = self.ln_f(x)
+        if self.cfg.native_ops and self.cfg.fuse_add_norm:
+            pending = None
+            for blk in self.h:
+                x, pending = blk.forward_deferred(x, pending)
+            _, x = self.ln_f.forward_add(x, pending)
+        else:
+            for blk in self.h:
+                x = blk(x)
+            x = self.ln_f(x)
         if targets is None:
             return F.linear(x[:, -1:, :], self.wte.weight)[..., : self.cfg.vocab_size]
         logits = F.linear(x, self.wte.weight)  # [B, T, padded vocab]: plain GEMM, vendor library

@@ -23,7 +23,7 @@ def _supported(x: torch.Tensor, cols: int, need_grad: bool) -> bool:
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, weight, bias, eps: float):
-        y, mean, rstd = _ext.C().layernorm_forward(x2, weight, bias, eps)
+        y, mean, rstd, _ = _ext.C().layernorm_forward(x2, weight, bias, eps)
         ctx.save_for_backward(x2, weight, mean, rstd)
         return y
 
@@ -32,6 +32,27 @@ class _LayerNorm(torch.autograd.Function):
         x2, weight, mean, rstd = ctx.saved_tensors
         dx, dg, db = _ext.C().layernorm_backward(dy.contiguous(), x2, weight, mean, rstd)
         return dx, dg, db, None
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(s, y) = (x + r, LN(x + r)) in one pass; the backward folds the gradient that reaches ``s``
+    from its other consumers (the residual stream) into the layer-norm gradient in one pass too.
+    ``x`` and ``r`` receive the same gradient tensor."""
+
+    @staticmethod
+    def forward(ctx, x2, r2, weight, bias, eps: float):
+        y, mean, rstd, s = _ext.C().layernorm_forward(x2, weight, bias, eps, r2)
+        ctx.save_for_backward(s, weight, mean, rstd)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, weight, mean, rstd = ctx.saved_tensors
+        if dy is None:  # only the sum was used downstream
+            return ds, ds, None, None, None
+        dres = ds.contiguous() if ds is not None else None
+        dx, dg, db = _ext.C().layernorm_backward(dy.contiguous(), s, weight, mean, rstd, dres)
+        return dx, dx, dg, db, None
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -46,6 +67,24 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     return _LayerNorm.apply(x2, weight.contiguous(), bias.contiguous(), eps).reshape(x.shape)
 
 
+def add_layer_norm(x: torch.Tensor, r, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
+    """Returns ``(s, y)`` with ``s = x + r`` and ``y = layer_norm(s)``; ``r`` may be ``None``
+    (then ``s`` is ``x``).  One kernel on the GPU in each direction instead of add + layer norm."""
+    if r is None:
+        return x, layer_norm(x, weight, bias, eps)
+    cols = x.shape[-1]
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or r.requires_grad or weight.requires_grad)
+    if (bias is None or not _supported(x, cols, need_grad) or weight.dtype != x.dtype or r.dtype != x.dtype
+            or r.shape != x.shape or r.device != x.device):
+        s = x + r
+        return s, F.layer_norm(s, (cols,), weight, bias, eps)
+    x2, r2 = x.reshape(-1, cols), r.reshape(-1, cols)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    r2 = r2 if r2.is_contiguous() else r2.contiguous()
+    s, y = _AddLayerNorm.apply(x2, r2, weight.contiguous(), bias.contiguous(), eps)
+    return s.reshape(x.shape), y.reshape(x.shape)
+
+
 class LayerNorm(nn.LayerNorm):
     """``nn.LayerNorm`` over the last dimension (same parameters and ``state_dict`` keys)."""
 
@@ -53,3 +92,10 @@ class LayerNorm(nn.LayerNorm):
         if len(self.normalized_shape) != 1 or self.weight is None:
             return super().forward(x)
         return layer_norm(x, self.weight, self.bias, self.eps)
+
+    def forward_add(self, x: torch.Tensor, r):
+        """``(x + r, self(x + r))`` fused; ``r`` may be ``None``."""
+        if len(self.normalized_shape) != 1 or self.weight is None:
+            s = x if r is None else x + r
+            return s, super().forward(s)
+        return add_layer_norm(x, r, self.weight, self.bias, self.eps)

@@ -472,3 +472,43 @@ def test_gemm_bf16_split_k_exact_integers(a_k, b_k, M, N, K):
     assert torch.equal(out.double(), ref)
     again = C().gemm(Aop, Bop, a_k, b_k)
     assert torch.equal(out, again)  # deterministic reduction order
+
+
+@pytest.mark.parametrize("rows,cols,dtype", [(300, 768, torch.bfloat16), (64, 1024, torch.bfloat16), (33, 256, torch.float32)])
+def test_add_layernorm_fused_matches_unfused(rows, cols, dtype):
+    """s = x + r, y = LN(s) in one kernel; backward folds the gradient arriving at s into dx."""
+    from distributed_pytorch_amd.ops.layernorm import add_layer_norm, layer_norm
+
+    torch.manual_seed(rows + cols)
+    x = torch.randn(rows, cols, device=DEV).to(dtype)
+    r = torch.randn(rows, cols, device=DEV).to(dtype)
+    g = torch.randn(cols, device=DEV).to(dtype)
+    b = torch.randn(cols, device=DEV).to(dtype)
+    gs_, gy_ = torch.randn(rows, cols, device=DEV).to(dtype), torch.randn(rows, cols, device=DEV).to(dtype)
+
+    def run(fused):
+        xs, rs, gg, bb = (t.clone().requires_grad_() for t in (x, r, g, b))
+        if fused:
+            s, y = add_layer_norm(xs, rs, gg, bb, 1e-5)
+        else:
+            s = xs + rs
+            y = layer_norm(s, gg, bb, 1e-5)
+        torch.autograd.backward([s, y], [gs_, gy_])
+        return s, y, xs.grad, rs.grad, gg.grad, bb.grad
+
+    fs, fy, fdx, fdr, fdg, fdb = run(True)
+    us, uy, udx, udr, udg, udb = run(False)
+    assert torch.equal(fs, us) and torch.equal(fy, uy)  # the sum is rounded before normalising, as unfused
+    t = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(fdx.float(), udx.float(), **t)
+    torch.testing.assert_close(fdr.float(), udr.float(), **t)
+    assert torch.equal(fdx, fdr)
+    torch.testing.assert_close(fdg.float(), udg.float(), **t)
+    torch.testing.assert_close(fdb.float(), udb.float(), **t)
+    # fp64 reference for the fused gradient of x
+    xr, rr = x.double().requires_grad_(), r.double().requires_grad_()
+    sr = xr + rr
+    yr = F.layer_norm(sr, (cols,), g.double(), b.double(), 1e-5)
+    torch.autograd.backward([sr, yr], [gs_.double(), gy_.double()])
+    t2 = dict(rtol=4e-2, atol=6e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(fdx.double(), xr.grad, **t2)

@@ -25,6 +25,7 @@ from torch.utils.data import DataLoader
 import distributed as dist
 from distributed_pytorch_amd.models.dummy import DummyDataset, DummyModel
 from distributed_pytorch_amd.ops import FusedAdamW, SoftmaxCrossEntropy
+from distributed_pytorch_amd.utils.data import DevicePrefetcher
 
 
 def build_parser():
@@ -72,8 +73,8 @@ def train(model, loader, criterion, optimizer, args):
     meter = EpochMeter(device) if args.quiet else None
     n_iters = 0
 
-    for it, (x, y) in enumerate(loader):
-        x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
+    # batches arrive on the device one step ahead (pinned staging + copy stream); CPU: pass-through
+    for it, (x, y) in enumerate(DevicePrefetcher(loader, device)):
 
         y_hat = model(x)
         loss = criterion(y_hat, y)
@@ -139,7 +140,7 @@ def main_worker(gpu, world_size, argv=None):
     dataset = DummyDataset(args.data_size, args.n_classes)
     sampler = dist.data_sampler(dataset, is_distributed, shuffle=False)
     loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=(sampler is None), sampler=sampler,
-                        pin_memory=(device.type == "cuda"))
+                        pin_memory=False)  # DevicePrefetcher stages through its own pinned ring
 
     """ Model """
     model = DummyModel(in_dim=1, hidden_dim=args.hidden_dim, n_classes=args.n_classes, native=native)

@@ -134,3 +134,23 @@ def test_cpu_slices_partition_affinity():
     sl = cpu_slices(2)
     assert len(sl) == 2 and not set(sl[0]) & set(sl[1])
     assert set(sl[0]) | set(sl[1]) <= set(cpus)
+
+
+def test_device_prefetcher_cpu_passthrough_preserves_batches_and_structure():
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from distributed_pytorch_amd.utils.data import DevicePrefetcher
+
+    ds = TensorDataset(torch.arange(10).float().unsqueeze(1), torch.arange(10))
+    loader = DataLoader(ds, batch_size=4, shuffle=False)
+    pf = DevicePrefetcher(loader, torch.device("cpu"))
+    assert len(pf) == 3
+    got = list(pf)
+    ref = list(loader)
+    assert len(got) == len(ref)
+    for (gx, gy), (rx, ry) in zip(got, ref):
+        assert torch.equal(gx, rx) and torch.equal(gy, ry)
+    # nested containers keep their structure
+    nested = [{"a": torch.ones(2), "b": (torch.zeros(1), 3)}]
+    out = list(DevicePrefetcher(nested, "cpu"))
+    assert isinstance(out[0], dict) and isinstance(out[0]["b"], tuple) and out[0]["b"][1] == 3

@@ -160,3 +160,23 @@ def test_native_extension_is_loaded_and_used():
     assert native_route(64, 4, 4096, torch.float32) == "skinny"
     assert native_route(256, 8192, 8192, torch.bfloat16) == "mfma"
     assert os.path.basename(_ext.C().__file__).startswith("_C")
+
+
+def test_device_prefetcher_delivers_exact_batches_on_device():
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from distributed_pytorch_amd.utils.data import DevicePrefetcher
+
+    torch.manual_seed(0)
+    xs, ys = torch.randn(1000, 33), torch.randint(0, 10, (1000,))
+    loader = DataLoader(TensorDataset(xs, ys), batch_size=96, shuffle=False)  # last batch is short: staging is re-sized
+    dev = torch.device("cuda:0")
+    seen = 0
+    for depth in (1, 2, 3):
+        for i, (x, y) in enumerate(DevicePrefetcher(loader, dev, depth=depth)):
+            assert x.device == dev and y.device == dev
+            lo = i * 96
+            # consume on the compute stream, as a training step would
+            assert torch.equal((x * 1).cpu(), xs[lo:lo + 96]) and torch.equal(y.cpu(), ys[lo:lo + 96])
+            seen += x.shape[0]
+    assert seen == 3000

@@ -47,6 +47,8 @@ def parse_args(argv=None):
     p.add_argument("--bucket-mb", type=float, default=None)
     p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
     p.add_argument("--stock", action="store_true", help="comparison run: stock torch ops and torch.optim.AdamW(fused=True)")
+    p.add_argument("--tuned-gemms", action="store_true", help="vendor GEMMs by the shipped TunableOp solution table instead of the library's default heuristic (measured: within 0.5 %% of the default)")
+    p.add_argument("--tune-gemms", default=None, metavar="CSV", help="time all vendor GEMM solutions for the shapes of this run and write the winners to CSV")
     p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph")
     p.add_argument("--json-out", default=None, help="also write the JSON line to this file")
     return p.parse_args(argv)
@@ -129,6 +131,24 @@ def run_rank(rank: int, world_size: int, argv):
     device = dist.get_device()
     if use_gpu:
         torch.cuda.set_device(device)
+        from distributed_pytorch_amd.utils import gemm_tuning
+
+        if args.tune_gemms:
+            gemm_tuning.record_tuned_gemms(args.tune_gemms if world_size == 1 else f"{args.tune_gemms}.rank{rank}")
+            if rank == 0:  # tuning a shape takes a while and prints nothing: keep a sign of life on stderr
+                import sys as _sys
+                import threading as _threading
+                import time as _time
+
+                def _heartbeat():
+                    t0 = _time.time()
+                    while True:
+                        _time.sleep(30)
+                        print(f"[tune-gemms] {_time.time() - t0:.0f}s", file=_sys.stderr, flush=True)
+
+                _threading.Thread(target=_heartbeat, daemon=True).start()
+        elif args.tuned_gemms and not args.stock:
+            gemm_tuning.enable_tuned_gemms()
     torch.manual_seed(0)
 
     model, loss_fn, per_gpu_batch, dtype, info = build_workload(args, device)
@@ -207,6 +227,7 @@ def run_rank(rank: int, world_size: int, argv):
             "optimizer": "torch.optim.AdamW(fused)" if args.stock else "FusedAdamW" + ("+fp32-master" if dtype != torch.float32 else ""),
             "stock_torch_ops": bool(args.stock),
             "linear_impl": args.linear_impl,
+            "vendor_gemm_table": bool(use_gpu and args.tuned_gemms and not (args.stock or args.tune_gemms)),
             "grad_reduce_dtype": (args.reduce_dtype or ("param dtype" if n > 1 else None)),
             "comm": (pg.get_backend() if n > 1 else None),
             "hip_graph": bool(graph is not None),

@@ -125,6 +125,13 @@ def _child_entry(worker_fn: Callable, rank: int, args: tuple, err_conn, cpus: Li
             os.sched_setaffinity(0, cpus)
         except OSError:
             pass
+    # Hang diagnosis: with DIST_HANG_DUMP_S=N every rank prints the Python stacks of all its threads
+    # to stderr every N seconds (a stuck collective then shows which rank waits where).
+    hang_s = os.environ.get("DIST_HANG_DUMP_S", "")
+    if hang_s not in ("", "0"):
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(hang_s), repeat=True, file=sys.stderr)
     try:
         worker_fn(rank, *args)
     except KeyboardInterrupt:
@@ -258,7 +265,12 @@ def spawn(worker_fn: Callable, args: tuple = (), nprocs: int = 1, *, env_per_ran
 
     old_handlers = {}
 
+    forwarding = [False]
+
     def _forward(signum, _frame):
+        if forwarding[0]:  # a second signal while the first is still being handled
+            return
+        forwarding[0] = True
         pc.terminate_all()
         raise KeyboardInterrupt(f"launcher received signal {signum}")
 
@@ -303,11 +315,18 @@ def launch(worker_fn: Callable, *args, nprocs: Optional[int] = None):
             ids = visible_device_ids(device_count)
             if ids is None:
                 raise ValueError("GPUs not specified. Please set HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is accepted too).")
-            if world_size > len(ids):
-                raise ValueError(f"world size {world_size} exceeds the {len(ids)} visible GPU(s): {','.join(ids)}")
             mode = os.environ.get("DIST_GPU_BINDING", "rotate")
-            for r in range(world_size):
-                env_per_rank[r].update(child_device_env(ids[:world_size], r, mode))
+            if world_size > len(ids):
+                # More ranks than GPUs is only meaningful for plumbing tests over gloo (RCCL refuses two
+                # ranks on one device), so it has to be asked for.
+                if os.environ.get("DIST_ALLOW_GPU_SHARING", "0") != "1":
+                    raise ValueError(f"world size {world_size} exceeds the {len(ids)} visible GPU(s): {','.join(ids)} "
+                                     "(set DIST_ALLOW_GPU_SHARING=1 to place several gloo ranks on one GPU)")
+                for r in range(world_size):
+                    env_per_rank[r].update(child_device_env(ids, r % len(ids), mode if mode != "index" else "rotate"))
+            else:
+                for r in range(world_size):
+                    env_per_rank[r].update(child_device_env(ids[:world_size], r, mode))
         store = Store("127.0.0.1", 0, is_host=True, bind_addr="127.0.0.1")
         try:
             common = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(store.port), "DIST_STORE_HOSTED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}

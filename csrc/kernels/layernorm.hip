@@ -179,23 +179,33 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
   }
 }
 
-// dgamma / dbeta = column sums of the per-workgroup partial rows.  32 outputs per workgroup,
-// 8 row groups x 32 columns of threads, LDS combine (see reduce_partials_kernel in skinny.hip).
+// dgamma / dbeta = column sums of the per-workgroup partial rows.  16 outputs per workgroup, 16 row
+// groups x 16 columns of threads (64-byte row segments), four independent loads in flight per
+// thread (the kernel is latency-bound: a thread walks nblocks/16 rows), LDS combine.
 template <typename TR>
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, typename TR::T* __restrict__ dgamma,
                                                                         typename TR::T* __restrict__ dbeta, int cols, int nblocks) {
-  __shared__ float red[8][33];
-  const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cc;
-  float s = 0.f;
-  if (c < 2 * cols)
-    for (int b = rg; b < nblocks; b += 8) s += partial[static_cast<size_t>(b) * 2 * cols + c];
-  red[rg][cc] = s;
+  __shared__ float red[16][17];
+  const int cc = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cc;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * cols) {
+    const size_t ld = static_cast<size_t>(2) * cols;
+    int b = rg;
+    for (; b + 48 < nblocks; b += 64) {
+      s0 += partial[static_cast<size_t>(b) * ld + c];
+      s1 += partial[static_cast<size_t>(b + 16) * ld + c];
+      s2 += partial[static_cast<size_t>(b + 32) * ld + c];
+      s3 += partial[static_cast<size_t>(b + 48) * ld + c];
+    }
+    for (; b < nblocks; b += 16) s0 += partial[static_cast<size_t>(b) * ld + c];
+  }
+  red[rg][cc] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && c < 2 * cols) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cc];
+    for (int k = 0; k < 16; ++k) t += red[k][cc];
     if (c < cols) dgamma[c] = TR::from_f32(t);
     else dbeta[c - cols] = TR::from_f32(t);
   }
@@ -255,7 +265,7 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const
                          static_cast<const T*>(dy), static_cast<const T*>(x), static_cast<const T*>(dres), static_cast<const T*>(gamma), mean,
                          rstd, static_cast<T*>(dx), workspace, rows, static_cast<int>(cols));
     });
-    hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((2 * cols + 31) / 32)), dim3(kThreads),
+    hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((2 * cols + 15) / 16)), dim3(kThreads),
                        0, stream, workspace, static_cast<T*>(dgamma), static_cast<T*>(dbeta), static_cast<int>(cols), blocks);
   });
 }

@@ -237,25 +237,34 @@ __global__ __launch_bounds__(kThreads) void skinny_n_wgrad_partial_kernel(const 
       for (int j = 0; j < V && k0 + j < K; ++j) out[n * K + k0 + j] = acc[n][j];
 }
 
-// out[i] = sum_c partial[c][i], i in [0, len).  A workgroup owns 32 consecutive outputs; its
-// 256 threads form 8 row groups x 32 columns, so every load instruction reads 128 contiguous
-// bytes per row and a thread walks only chunks/8 rows; LDS combines the 8 row groups.
+// out[i] = sum_c partial[c][i], i in [0, len).  A workgroup owns 16 consecutive outputs; its 256
+// threads form 16 row groups x 16 columns (64-byte row segments), each thread keeps four
+// independent loads in flight while it walks chunks/16 rows (the kernel is latency-bound), and LDS
+// combines the 16 row groups.
 template <typename TR>
 __global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* __restrict__ partial,
                                                                    typename TR::T* __restrict__ out, long long len,
                                                                    int chunks) {
-  __shared__ float red[8][33];
-  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const long long i = static_cast<long long>(blockIdx.x) * 32 + c;
-  float s = 0.f;
-  if (i < len)
-    for (int r = rg; r < chunks; r += 8) s += partial[static_cast<long long>(r) * len + i];
-  red[rg][c] = s;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const long long i = static_cast<long long>(blockIdx.x) * 16 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < len) {
+    int r = rg;
+    for (; r + 48 < chunks; r += 64) {
+      s0 += partial[static_cast<long long>(r) * len + i];
+      s1 += partial[static_cast<long long>(r + 16) * len + i];
+      s2 += partial[static_cast<long long>(r + 32) * len + i];
+      s3 += partial[static_cast<long long>(r + 48) * len + i];
+    }
+    for (; r < chunks; r += 16) s0 += partial[static_cast<long long>(r) * len + i];
+  }
+  red[rg][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && i < len) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][c];
+    for (int k = 0; k < 16; ++k) t += red[k][c];
     out[i] = TR::from_f32(t);
   }
 }
@@ -398,7 +407,7 @@ void col_reduce(const void* dy, const void* aux, void* g, void* db, void* dw, fl
   } else
   hipLaunchKernelGGL((col_reduce_partial_kernel<TR, MODE>), dim3(col_tiles, chunks), dim3(kThreads), 0, stream,
                      static_cast<const T*>(dy), static_cast<const T*>(aux), static_cast<T*>(g), pb, pw, M, N, rpc, act);
-  const int rb = static_cast<int>((N + 31) / 32);
+  const int rb = static_cast<int>((N + 15) / 16);
   if (db)
     hipLaunchKernelGGL((reduce_partials_kernel<TR>), dim3(rb), dim3(kThreads), 0, stream, pb, static_cast<T*>(db), N, chunks);
   if (MODE == kOuterWgrad && dw)
@@ -484,7 +493,7 @@ void launch_skinny_n_wgrad(const void* dy, const void* x, void* dW, void* db, fl
     else if (N <= 8) go(std::integral_constant<int, 8>{});
     else go(std::integral_constant<int, 16>{});
     const long long len = N * K;
-    hipLaunchKernelGGL((reduce_partials_kernel<TR>), dim3(static_cast<unsigned>((len + 31) / 32)),
+    hipLaunchKernelGGL((reduce_partials_kernel<TR>), dim3(static_cast<unsigned>((len + 15) / 16)),
                        dim3(kThreads), 0, stream, workspace, static_cast<T*>(dW), len, chunks);
     if (db) col_reduce<TR, kColSum>(dy, nullptr, nullptr, db, nullptr, workspace + static_cast<long long>(chunks) * len, M, N, 0, stream);
   });

@@ -2,6 +2,7 @@
 group: every query / collective degrades to the single-process answer, exactly as the
 reference helper does (reference distributed.py:69-101, 119-187)."""
 import inspect
+import os
 import io
 import socket
 from contextlib import redirect_stdout
@@ -154,3 +155,53 @@ def test_device_prefetcher_cpu_passthrough_preserves_batches_and_structure():
     nested = [{"a": torch.ones(2), "b": (torch.zeros(1), 3)}]
     out = list(DevicePrefetcher(nested, "cpu"))
     assert isinstance(out[0], dict) and isinstance(out[0]["b"], tuple) and out[0]["b"][1] == 3
+
+
+def test_launcher_refuses_more_ranks_than_gpus_unless_sharing_is_requested(monkeypatch):
+    """World size above the visible GPU count is an error (RCCL cannot place two ranks on one
+    device); DIST_ALLOW_GPU_SHARING=1 maps ranks round-robin for gloo plumbing runs."""
+    from distributed_pytorch_amd.parallel import launcher
+
+    env = launcher.child_device_env(["3", "5"], 1, "rotate")
+    assert env["HIP_VISIBLE_DEVICES"] == "5,3" and env["DIST_LOCAL_DEVICE"] == "0"
+    assert launcher.child_device_env(["3", "5"], 0, "exclusive")["HIP_VISIBLE_DEVICES"] == "3"
+    assert launcher.child_device_env(["3", "5"], 1, "index") == {"DIST_LOCAL_DEVICE": "1"}
+    with pytest.raises(ValueError):
+        launcher.child_device_env(["0"], 0, "bogus")
+
+    calls = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    monkeypatch.delenv("DIST_ALLOW_GPU_SHARING", raising=False)
+    with pytest.raises(ValueError, match="exceeds"):
+        launcher.launch(lambda *a: None, nprocs=2)
+
+    def fake_spawn(fn, args, nprocs, env_per_rank, pin_cpus, join):
+        calls["env"] = env_per_rank
+
+    monkeypatch.setattr(launcher, "spawn", fake_spawn)
+    monkeypatch.setenv("DIST_ALLOW_GPU_SHARING", "1")
+    launcher.launch(lambda *a: None, nprocs=3)
+    assert [e["HIP_VISIBLE_DEVICES"] for e in calls["env"]] == ["0", "0", "0"]
+    assert all(e["MASTER_ADDR"] == "127.0.0.1" and e["DIST_STORE_HOSTED"] == "1" for e in calls["env"])
+
+
+def test_gemm_tuning_is_inert_without_a_gpu_and_profile_summaries_parse(tmp_path):
+    from distributed_pytorch_amd.bench import profile
+    from distributed_pytorch_amd.utils import gemm_tuning
+
+    assert os.path.isfile(gemm_tuning.default_table())
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable_tuned_gemms() is False
+    # counter CSV in rocprofv3's layout -> per-kernel averages and derived MFMA utilisation
+    p = tmp_path / "c.csv"
+    hdr = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
+    rows = []
+    for d in (1, 2):
+        for name, val in (("GRBM_GUI_ACTIVE", 8 * 1000.0), ("SQ_VALU_MFMA_BUSY_CYCLES", 512000.0)):
+            rows.append(f'{d},{d},"Agent 1",1,1,1,64,1,"dpa::k(int)",256,0,0,64,0,32,{name},{val},{1000 * d},{1000 * d + 500}\n')
+    rows.append('3,3,"Agent 1",1,1,1,64,2,"other_kernel",256,0,0,64,0,32,GRBM_GUI_ACTIVE,1.0,0,10\n')
+    p.write_text(hdr + "".join(rows))
+    out = profile.pmc_summary(str(p), "dpa::")
+    assert len(out) == 1 and out[0]["dispatches"] == 2 and out[0]["avg_us"] == 0.5
+    assert out[0]["mfma_busy_pct"] == 50.0  # 512000 / (1000 cycles * 1024 SIMDs)

@@ -395,6 +395,58 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
       }
     return;
   }
+  // Epilogue.  Straight from the accumulators a wave-wide store covers 16 rows x 32 bytes, which the
+  // memory system handles at about a third of its streaming rate (the epilogue alone used to take as
+  // long as ten k-steps).  Full interior tiles therefore go through LDS, which is free once the
+  // last k-step is done: each wave transposes its 128 x 64 sub-tile in two halves of 64 rows
+  // (144-byte row pitch: conflict-free 8-byte writes and 16-byte reads) and writes 8 rows x 128
+  // contiguous bytes per store instruction.  Bias and activation are applied in registers first.
+  // (A persistent one-workgroup-per-CU variant that requests the next tile's first k-step before the
+  // epilogue was measured 10-20 % slower: its top-of-loop vmcnt(0) also waits for the output stores
+  // to drain, which the hardware overlaps for free when a fresh workgroup takes over the CU.)
+  const bool staged = p.pre_act == nullptr && p.beta == 0.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+  if (staged) {
+    constexpr int kPitch = 144;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // every wave has finished reading the operand stages
+    __builtin_amdgcn_sched_barrier(0);
+    char* mine = smem2 + wid * (64 * kPitch);
+    const u16* bias = static_cast<const u16*>(p.bias);
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
+      if (bias) {
+        const u16x4 b4 = *reinterpret_cast<const u16x4*>(bias + n0 + wn + 16 * j + 4 * (lane >> 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[j][e] = BF16::to_f32(b4[e]);
+      }
+    }
+    u16* C = static_cast<u16*>(p.C);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4& a = acc[4 * half + ii][j];
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(act_fn(p.alpha * a[e] + bv[j][e], p.act));
+          *reinterpret_cast<u16x4*>(mine + (16 * ii + (lane & 15)) * kPitch + (16 * j + 4 * (lane >> 4)) * 2) = o;
+        }
+      // the wave reads back only what it wrote itself: no workgroup barrier, just the LDS counter
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rl = 8 * it + (lane >> 3), ch = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(mine + rl * kPitch + ch * 16);
+        *reinterpret_cast<u32x4*>(C + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll

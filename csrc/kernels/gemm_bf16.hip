@@ -76,14 +76,14 @@ __device__ __forceinline__ void store_tile_bf16(const GemmArgs& p, const f32x4& 
     }
     u16x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(act_fn(v[e], p.act));
+    for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(act_fn(BF16::to_f32(BF16::from_f32(v[e])), p.act));  // activation of the value as stored
     *reinterpret_cast<u16x4*>(cp) = o;
   } else {
     for (int e = 0; e < 4 && col0 + e < p.N; ++e) {
       float x = v[e] + (bias ? BF16::to_f32(bias[col0 + e]) : 0.f);
       if (p.beta != 0.f) x += p.beta * BF16::to_f32(C[row * p.ldc + col0 + e]);
       if (P) P[row * p.ldc + col0 + e] = BF16::from_f32(x);
-      C[row * p.ldc + col0 + e] = BF16::from_f32(act_fn(x, p.act));
+      C[row * p.ldc + col0 + e] = BF16::from_f32(act_fn(BF16::to_f32(BF16::from_f32(x)), p.act));
     }
   }
 }
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
   // (A persistent one-workgroup-per-CU variant that requests the next tile's first k-step before the
   // epilogue was measured 10-20 % slower: its top-of-loop vmcnt(0) also waits for the output stores
   // to drain, which the hardware overlaps for free when a fresh workgroup takes over the CU.)
-  const bool staged = p.pre_act == nullptr && p.beta == 0.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
-                      (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+  const bool staged = p.beta == 0.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_act)) & 15) == 0;
   if (staged) {
     constexpr int kPitch = 144;
     __builtin_amdgcn_sched_barrier(0);
@@ -424,9 +424,8 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
         for (int e = 0; e < 4; ++e) bv[j][e] = BF16::to_f32(b4[e]);
       }
     }
-    u16* C = static_cast<u16*>(p.C);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    // one pass per output tensor: the pre-activation (when the backward will need it), then the result
+    auto emit = [&](u16* out, int half, bool activate) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -434,16 +433,25 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
           const f32x4& a = acc[4 * half + ii][j];
           u16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(act_fn(p.alpha * a[e] + bv[j][e], p.act));
+          for (int e = 0; e < 4; ++e) {
+            // the pre-activation is rounded to bf16 first, exactly as the unfused path stores and re-reads it
+            const float v = BF16::to_f32(BF16::from_f32(p.alpha * a[e] + bv[j][e]));
+            o[e] = BF16::from_f32(activate ? act_fn(v, p.act) : v);
+          }
           *reinterpret_cast<u16x4*>(mine + (16 * ii + (lane & 15)) * kPitch + (16 * j + 4 * (lane >> 4)) * 2) = o;
         }
-      // the wave reads back only what it wrote itself: no workgroup barrier, just the LDS counter
+      // the wave reads back only what it wrote itself, and the LDS serves one wave's requests in order
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int rl = 8 * it + (lane >> 3), ch = lane & 7;
         const u32x4 v = *reinterpret_cast<const u32x4*>(mine + rl * kPitch + ch * 16);
-        *reinterpret_cast<u32x4*>(C + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
+        *reinterpret_cast<u32x4*>(out + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
       }
+    };
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (p.pre_act) emit(static_cast<u16*>(p.pre_act), half, false);
+      emit(static_cast<u16*>(p.C), half, true);
     }
     return;
   }

@@ -73,6 +73,12 @@ void launch_xent_bwd(const void* logits, int dtype, const long long* targets, co
                      const float* grad_out, const float* metrics, int mean, long long N,
                      long long C, long long ld, long long ignore_index, void* dlogits,
                      hipStream_t stream);
+// Fused forward + backward for training: `logits` [N, ld] is overwritten with
+// (softmax - onehot) * scale, scale = 1/#counted rows (mean) or 1 (sum), written to grad_scale[0].
+bool xent_fused_supported(long long C);
+void launch_xent_fused(void* logits, int dtype, const long long* targets, long long N, long long C,
+                       long long ld, long long ignore_index, int mean, float* grad_scale,
+                       float* row_loss, unsigned char* correct, hipStream_t stream);
 
 // ------------------------------------------------------------------ dense layers
 enum Act : int { kActNone = 0, kActRelu = 1, kActGelu = 2 };

@@ -77,16 +77,24 @@ __global__ __launch_bounds__(256) void xent_bwd_small_kernel(const typename TR::
 }
 
 // ---------------------------------------------------------------- large C: workgroup per row
-template <typename TR, int THREADS>
-__global__ __launch_bounds__(THREADS) void xent_fwd_row_kernel(const typename TR::T* __restrict__ logits,
+// FUSE_BWD (training): the same workgroup then walks its row a second time and writes
+// (softmax - onehot) * grad_scale[0] to `dlogits` (which may be the logits buffer itself).  The row
+// was read a moment ago, and with 1024-thread workgroups only ~512 rows of 100 KB are in flight on
+// the chip, so the second read is served by the L2 / Infinity Cache: the [tokens, vocabulary] tensor
+// crosses HBM twice (read, write) instead of three times as with separate forward and backward passes.
+template <typename TR, int THREADS, bool FUSE_BWD = false>
+__global__ __launch_bounds__(THREADS) void xent_fwd_row_kernel(const typename TR::T* logits,
                                                                const long long* __restrict__ targets, long long C,
                                                                long long ld, long long ignore_index,
                                                                float* __restrict__ row_loss, float* __restrict__ row_lse,
-                                                               unsigned char* __restrict__ correct) {
+                                                               unsigned char* __restrict__ correct,
+                                                               const float* __restrict__ grad_scale = nullptr,
+                                                               typename TR::T* dlogits = nullptr) {
   constexpr int V = TR::kVec;
   constexpr int NW = THREADS / 64;
   __shared__ float s_m[NW], s_s[NW];
   __shared__ long long s_a[NW];
+  __shared__ float s_stats[2];
   const long long r = blockIdx.x;
   const typename TR::T* row = logits + r * ld;
   const long long tgt = targets[r];
@@ -180,11 +188,49 @@ __global__ __launch_bounds__(THREADS) void xent_fwd_row_kernel(const typename TR
     }
     const float ls = __logf(S);
     const bool ignored = (tgt == ignore_index) || tgt < 0 || tgt >= C;
-    row_lse[2 * r] = M;
-    row_lse[2 * r + 1] = ls;
+    if (row_lse) {
+      row_lse[2 * r] = M;
+      row_lse[2 * r + 1] = ls;
+    }
     row_loss[r] = ignored ? 0.f : (M - TR::to_f32(row[tgt])) + ls;
     correct[r] = (!ignored && A == tgt) ? 1 : 0;
+    if (FUSE_BWD) {
+      s_stats[0] = M;
+      s_stats[1] = ls;
+    }
   }
+  if (FUSE_BWD) {
+    __syncthreads();  // statistics are published, and row[tgt] was read before the row is overwritten
+    const float mx = s_stats[0], ls = s_stats[1];
+    const bool ignored = (tgt == ignore_index) || tgt < 0 || tgt >= C;
+    const float g = ignored ? 0.f : grad_scale[0];
+    typename TR::T* out = dlogits + r * ld;
+    const bool aligned2 = ((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const long long nvec2 = aligned2 ? C / V : 0;
+    for (long long k = threadIdx.x; k < nvec2; k += THREADS) {
+      float a[V];
+      load_as_f32<TR, V>(row + k * V, a);
+      const long long j0 = k * V;
+#pragma unroll
+      for (int j = 0; j < V; ++j) a[j] = (__expf((a[j] - mx) - ls) - ((j0 + j) == tgt ? 1.f : 0.f)) * g;
+      store_from_f32<TR, V>(out + k * V, a);
+    }
+    for (long long j = nvec2 * V + threadIdx.x; j < ld; j += THREADS) {
+      float d = 0.f;
+      if (j < C) d = (__expf((TR::to_f32(row[j]) - mx) - ls) - (j == tgt ? 1.f : 0.f)) * g;
+      out[j] = TR::from_f32(d);
+    }
+  }
+}
+
+// grad_scale[0] = 1 / max(#targets != ignore_index, 1) for a mean, 1 for a sum.
+__global__ __launch_bounds__(1024) void xent_scale_kernel(const long long* __restrict__ targets, long long N, long long ignore_index,
+                                                          int mean, float* __restrict__ grad_scale) {
+  __shared__ float scratch[16];
+  float valid = 0.f;
+  for (long long i = threadIdx.x; i < N; i += 1024) valid += (targets[i] != ignore_index) ? 1.f : 0.f;
+  valid = block_sum<16>(valid, scratch);
+  if (threadIdx.x == 0) grad_scale[0] = mean ? 1.f / fmaxf(valid, 1.f) : 1.f;
 }
 
 template <typename TR, int THREADS>
@@ -290,6 +336,27 @@ void launch_xent_bwd(const void* logits, int dtype, const long long* targets, co
     } else {
       hipLaunchKernelGGL((xent_bwd_row_kernel<TR, 256>), dim3(static_cast<unsigned>(N)), dim3(256), 0, stream, lg, targets,
                          row_lse, grad_out, metrics, mean, C, ld, ignore_index, dl);
+    }
+  });
+}
+
+bool xent_fused_supported(long long C) { return C > kSmallC; }
+
+void launch_xent_fused(void* logits, int dtype, const long long* targets, long long N, long long C, long long ld,
+                       long long ignore_index, int mean, float* grad_scale, float* row_loss, unsigned char* correct,
+                       hipStream_t stream) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(xent_scale_kernel, dim3(1), dim3(1024), 0, stream, targets, N, ignore_index, mean, grad_scale);
+  dispatch_dtype(dtype, [&](auto tr) {
+    using TR = decltype(tr);
+    using T = typename TR::T;
+    T* lg = static_cast<T*>(logits);
+    if (C <= 4096) {
+      hipLaunchKernelGGL((xent_fwd_row_kernel<TR, 256, true>), dim3(static_cast<unsigned>(N)), dim3(256), 0, stream, lg, targets, C, ld,
+                         ignore_index, row_loss, static_cast<float*>(nullptr), correct, grad_scale, lg);
+    } else {
+      hipLaunchKernelGGL((xent_fwd_row_kernel<TR, 1024, true>), dim3(static_cast<unsigned>(N)), dim3(1024), 0, stream, lg, targets, C, ld,
+                         ignore_index, row_loss, static_cast<float*>(nullptr), correct, grad_scale, lg);
     }
   });
 }

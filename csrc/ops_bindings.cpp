@@ -247,6 +247,31 @@ Tensor xent_backward(Tensor logits, Tensor targets, Tensor row_lse, Tensor grad_
   return dlogits;
 }
 
+// Training-only fused pass: overwrites `logits` with d(loss)/d(logits) for a unit upstream gradient
+// (mean or sum reduction) and returns (correct, metrics); metrics = {loss sum, #correct, #counted, mean loss}.
+std::tuple<Tensor, Tensor> xent_fused(Tensor logits, Tensor targets, int64_t n_classes, int64_t ignore_index, bool mean) {
+  check_gpu(logits, "logits");
+  check_gpu(targets, "targets");
+  TORCH_CHECK(logits.dim() == 2 && logits.is_contiguous(), "xent_fused: logits must be a contiguous [N, C] tensor");
+  TORCH_CHECK(targets.dim() == 1 && targets.size(0) == logits.size(0) && targets.scalar_type() == at::kLong, "xent_fused: targets must be int64 [N]");
+  TORCH_CHECK(targets.get_device() == logits.get_device(), "logits and targets on different devices");
+  const int64_t N = logits.size(0), ld = logits.size(1);
+  const int64_t C = n_classes > 0 ? n_classes : ld;
+  TORCH_CHECK(C <= ld && N < (1ll << 31), "xent_fused: bad sizes");
+  TORCH_CHECK(kernels::xent_fused_supported(C), "xent_fused: needs more than 64 classes");
+  auto fopt = logits.options().dtype(at::kFloat);
+  Tensor row_loss = at::empty({N}, fopt), scale = at::empty({1}, fopt), metrics = at::empty({4}, fopt);
+  Tensor correct = at::empty({N}, logits.options().dtype(at::kBool));
+  DevGuard g(logits);
+  hipStream_t s = stream_of(logits);
+  const long long* tg = reinterpret_cast<const long long*>(targets.data_ptr<int64_t>());
+  kernels::launch_xent_fused(logits.data_ptr(), kdtype(logits), tg, N, C, ld, ignore_index, mean ? 1 : 0, scale.data_ptr<float>(),
+                             row_loss.data_ptr<float>(), reinterpret_cast<unsigned char*>(correct.data_ptr<bool>()), s);
+  kernels::launch_xent_reduce(row_loss.data_ptr<float>(), reinterpret_cast<const unsigned char*>(correct.data_ptr<bool>()), tg, N,
+                              ignore_index, metrics.data_ptr<float>(), s);
+  return {correct, metrics};
+}
+
 // ------------------------------------------------------------------ linear layers
 bool gemm_path_ok(const kernels::GemmArgs& a, int dt) {
   return dt == kernels::kF32 ? kernels::gemm_f32_supported(a) : (dt == kernels::kBF16 ? kernels::gemm_bf16_supported(a) : false);
@@ -546,6 +571,7 @@ void init_ops(py::module_& m) {
     a.lda = a_kmajor ? K : M; a.ldb = b_kmajor ? K : N; a.ldc = N;
     return kernels::gemm_bf16_split_k(a);
   }, "contraction ranges the bf16 GEMM would use for an [M,K]x[K,N] product (1 = single pass)");
+  m.def("xent_fused", &xent_fused, py::arg("logits"), py::arg("targets"), py::arg("n_classes"), py::arg("ignore_index"), py::arg("mean"));
   m.def("attention_supported", [](int64_t T, int64_t hd, int64_t rs) { return kernels::attention_supported(T, hd, rs); });
   m.def("multi_copy_scale", &multi_copy_scale, py::arg("srcs"), py::arg("dsts"), py::arg("scale") = 1.0);
   m.def("scale_inplace", &scale_inplace);

@@ -26,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.attention import causal_attention_qkvpacked
-from ..ops.cross_entropy import softmax_cross_entropy
+from ..ops.cross_entropy import projection_cross_entropy, softmax_cross_entropy
 from ..ops.layernorm import LayerNorm
 from ..ops.linear import library_linear_bias_act, linear_bias_act
 
@@ -45,6 +45,7 @@ class GPT2Config:
     native_ops: bool = True       # False: stock torch layer norm / GELU / cross-entropy (comparison baseline)
     attention_impl: str = "auto"  # auto | native | sdpa
     fuse_add_norm: bool = True    # fold each residual add into the layer norm that follows it
+    fused_lm_head_loss: bool = True  # lm-head GEMM + loss + logits gradient as one autograd node
 
     @property
     def padded_vocab_size(self) -> int:
@@ -181,11 +182,16 @@ class GPT2(nn.Module):
             x = self.ln_f(x)
         if targets is None:
             return F.linear(x[:, -1:, :], self.wte.weight)[..., : self.cfg.vocab_size]
-        logits = F.linear(x, self.wte.weight)  # [B, T, padded vocab]: plain GEMM, vendor library
         if not self.cfg.native_ops:
+            logits = F.linear(x, self.wte.weight)
             lg = logits.view(B * T, -1)[:, : self.cfg.vocab_size]
             return F.cross_entropy(lg.float(), targets.reshape(-1))
-        r = softmax_cross_entropy(logits.view(B * T, -1), targets.reshape(-1), n_classes=self.cfg.vocab_size,
-                                  inplace_backward=self.cfg.inplace_loss_backward)
+        if self.cfg.fused_lm_head_loss:
+            # vocabulary projection + loss + d(logits) as one node: the logits cross HBM twice, not three times
+            r = projection_cross_entropy(x, self.wte.weight, targets, n_classes=self.cfg.vocab_size)
+        else:
+            logits = F.linear(x, self.wte.weight)  # [B, T, padded vocab]: plain GEMM, vendor library
+            r = softmax_cross_entropy(logits.view(B * T, -1), targets.reshape(-1), n_classes=self.cfg.vocab_size,
+                                      inplace_backward=self.cfg.inplace_loss_backward)
         self.last_correct, self.last_metrics = r.correct, r.metrics
         return r.loss

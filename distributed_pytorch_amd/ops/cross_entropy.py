@@ -54,6 +54,56 @@ class _SoftmaxXent(torch.autograd.Function):
         return d, None, None, None, None, None
 
 
+class _ProjectionXent(torch.autograd.Function):
+    """loss(x @ W^T): the vocabulary projection and its loss as ONE autograd node, so that the
+    gradient of the logits can be written by the same kernel launch that computes the loss (each
+    workgroup walks its row twice, the second time out of cache).  The node's backward is then only
+    the two GEMMs; an upstream gradient other than 1 scales their (small) outputs instead of the
+    [tokens, vocabulary] tensor."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, targets, reduction: str, ignore_index: int, n_classes: int):
+        C = _ext.C()
+        logits = torch.mm(x2, weight.t())  # plain GEMM: vendor library
+        correct, metrics = C.xent_fused(logits, targets, n_classes, ignore_index, reduction == "mean")
+        ctx.save_for_backward(x2, weight, logits)  # `logits` now holds d loss / d logits for a unit upstream gradient
+        ctx.mark_non_differentiable(correct, metrics)
+        loss = (metrics[3] if reduction == "mean" else metrics[0]).clone()
+        return loss, correct, metrics
+
+    @staticmethod
+    def backward(ctx, dloss, _dcorrect, _dmetrics):
+        x2, weight, dlogits = ctx.saved_tensors
+        g = dloss.detach().to(dlogits.dtype)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dlogits, weight).mul_(g)
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(dlogits.t(), x2).mul_(g)
+        return dx, dw, None, None, None, None
+
+
+def projection_cross_entropy(x: torch.Tensor, weight: torch.Tensor, targets: torch.Tensor, reduction: str = "mean",
+                             ignore_index: int = -100, n_classes: Optional[int] = None) -> XentResult:
+    """Cross-entropy of ``x @ weight.T`` (``x``: [..., K], ``weight``: [C, K]) against ``targets``.
+
+    On the GPU the logits exist only inside the op: they are written by the GEMM, turned into
+    their own gradient in place by the fused loss kernel and consumed by the two backward GEMMs.
+    ``n_classes`` < C marks trailing rows of ``weight`` as padding.  reduction: mean | sum.
+    """
+    if reduction not in ("mean", "sum"):
+        raise ValueError(f"reduction must be mean | sum, got {reduction}")
+    x2 = x.reshape(-1, x.shape[-1])
+    t1 = targets.reshape(-1)
+    nc = weight.shape[0] if n_classes is None else int(n_classes)
+    fused_ok = (x2.is_cuda and x2.dtype == weight.dtype and x2.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                and nc > 64 and _ext.have_C())
+    if not fused_ok:
+        return softmax_cross_entropy(F.linear(x2, weight), t1, reduction, ignore_index, nc, inplace_backward=True)
+    loss, correct, metrics = _ProjectionXent.apply(x2.contiguous(), weight, t1.contiguous(), reduction, ignore_index, nc)
+    return XentResult(loss, correct, metrics)
+
+
 def softmax_cross_entropy(logits: torch.Tensor, targets: torch.Tensor, reduction: str = "mean", ignore_index: int = -100,
                           n_classes: Optional[int] = None, inplace_backward: bool = False) -> XentResult:
     """Cross-entropy of ``logits[N, C]`` against class indices ``targets[N]``.

@@ -512,3 +512,37 @@ def test_add_layernorm_fused_matches_unfused(rows, cols, dtype):
     torch.autograd.backward([sr, yr], [gs_.double(), gy_.double()])
     t2 = dict(rtol=4e-2, atol=6e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(fdx.double(), xr.grad, **t2)
+
+
+@pytest.mark.parametrize("N,K,V,nc,dtype", [(300, 64, 1000, 1000, torch.float32), (257, 128, 50304, 50257, torch.bfloat16),
+                                             (64, 32, 2048, 2000, torch.bfloat16), (33, 16, 130, 129, torch.float32)])
+def test_projection_cross_entropy_fused_matches_reference(N, K, V, nc, dtype):
+    """lm-head GEMM + loss + logits gradient as one node (gradient written over the logits by the
+    loss kernel itself) against fp64 autograd, including ignored rows, padding classes, rows whose
+    length is not a multiple of the vector width, and a non-unit upstream gradient."""
+    from distributed_pytorch_amd.ops.cross_entropy import projection_cross_entropy
+
+    torch.manual_seed(N + V)
+    x = (torch.randn(N, K, device=DEV) * 0.5).to(dtype)
+    w = (torch.randn(V, K, device=DEV) * 0.5).to(dtype)
+    t = torch.randint(0, nc, (N,), device=DEV)
+    t[::7] = -100
+    xs, ws = x.clone().requires_grad_(), w.clone().requires_grad_()
+    r = projection_cross_entropy(xs, ws, t, n_classes=nc)
+    (r.loss * 3.0).backward()
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    logits = (xr @ wr.t())[:, :nc]
+    ref = F.cross_entropy(logits, t, ignore_index=-100)
+    (ref * 3.0).backward()
+    tl = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(r.loss.double(), ref.detach(), **tl)
+    valid = t != -100
+    ref_correct = (logits.argmax(1) == t) & valid
+    if dtype == torch.float32:
+        assert torch.equal(r.correct, ref_correct)
+    assert not r.correct[~valid].any()
+    assert abs(float(r.metrics[2]) - float(valid.sum())) < 0.5
+    tg = dict(rtol=3e-2, atol=3e-3) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(xs.grad.double(), xr.grad, **tg)
+    torch.testing.assert_close(ws.grad.double(), wr.grad, **tg)
+    assert torch.count_nonzero(ws.grad[nc:].float()) == 0  # padding classes get no gradient

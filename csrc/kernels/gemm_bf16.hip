@@ -403,7 +403,10 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
   // contiguous bytes per store instruction.  Bias and activation are applied in registers first.
   // (A persistent one-workgroup-per-CU variant that requests the next tile's first k-step before the
   // epilogue was measured 10-20 % slower: its top-of-loop vmcnt(0) also waits for the output stores
-  // to drain, which the hardware overlaps for free when a fresh workgroup takes over the CU.)
+  // to drain, which the hardware overlaps for free when a fresh workgroup takes over the CU.  A
+  // 128x256x32 tile with two independent 4-wave workgroups per CU, meant to cover one workgroup's
+  // prologue / epilogue with the other's main loop, was 7-20 % slower as well: half the MFMAs per
+  // barrier and 1.5x the global->LDS traffic per flop cost more than the overlap returns.)
   const bool staged = p.beta == 0.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
                       ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_act)) & 15) == 0;
   if (staged) {

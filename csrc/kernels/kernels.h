@@ -144,15 +144,17 @@ void launch_act_bwd(const void* dy, const void* saved, void* g, void* db, float*
                     long long M, long long N, int dtype, int act, hipStream_t stream);
 
 // ------------------------------------------------------------------ layer norm
-// With `res` != nullptr: s = x + res is written to `sum_out` and y = LN(s); else y = LN(x).
-void launch_layernorm_fwd(const void* x, const void* res, void* sum_out, const void* gamma,
-                          const void* beta, void* y, float* mean, float* rstd, long long rows,
-                          long long cols, float eps, int dtype, hipStream_t stream);
+// With `res` != nullptr: s = x + res (+ res_bias, a [cols] vector) is written to `sum_out` and
+// y = LN(s); else y = LN(x).
+void launch_layernorm_fwd(const void* x, const void* res, const void* res_bias, void* sum_out,
+                          const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                          long long rows, long long cols, float eps, int dtype, hipStream_t stream);
 long long layernorm_bwd_workspace(long long rows, long long cols);
 // dx = LN'(dy) (+ dres when given: the gradient reaching the normalised tensor by another path).
+// dsum != nullptr: also the column sums of dx (gradient of res_bias); needs cols <= 1365.
 void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const void* gamma,
                           const float* mean, const float* rstd, void* dx, void* dgamma, void* dbeta,
-                          float* workspace, long long rows, long long cols, int dtype,
+                          void* dsum, float* workspace, long long rows, long long cols, int dtype,
                           hipStream_t stream);
 
 // ------------------------------------------------------------------ causal attention (head dim 64, bf16)

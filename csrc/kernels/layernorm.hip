@@ -28,6 +28,7 @@ constexpr int kMaxBlocks = 2048;
 template <typename TR, int MAXV>
 __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename TR::T* __restrict__ x,
                                                                  const typename TR::T* __restrict__ res,
+                                                                 const typename TR::T* __restrict__ res_bias,
                                                                  typename TR::T* __restrict__ sum_out,
                                                                  const typename TR::T* __restrict__ gamma,
                                                                  const typename TR::T* __restrict__ beta,
@@ -50,6 +51,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
         if (res) {
           float r[V];
           load_as_f32<TR, V>(res + row * cols + vi * V, r);
+          if (res_bias) {  // the bias of the layer that produced `res`, added here instead of in its GEMM
+            float rb[V];
+            load_as_f32<TR, V>(res_bias + vi * V, rb);
+#pragma unroll
+            for (int j = 0; j < V; ++j) r[j] = TR::to_f32(TR::from_f32(r[j] + rb[j]));
+          }
 #pragma unroll
           for (int j = 0; j < V; ++j) v[i][j] = TR::to_f32(TR::from_f32(v[i][j] + r[j]));
           store_from_f32<TR, V>(sum_out + row * cols + vi * V, v[i]);
@@ -91,7 +98,9 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
   }
 }
 
-template <typename TR, int MAXV>
+// DSUM: also accumulate the column sums of dx (the gradient of a bias that was added to the
+// residual operand in the forward); the partial rows then hold 3*cols values instead of 2*cols.
+template <typename TR, int MAXV, bool DSUM>
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename TR::T* __restrict__ dy,
                                                                  const typename TR::T* __restrict__ x,
                                                                  const typename TR::T* __restrict__ dres,
@@ -100,18 +109,22 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
                                                                  typename TR::T* __restrict__ dx, float* __restrict__ partial,
                                                                  long long rows, int cols) {
   constexpr int V = TR::kVec;
-  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [kWaves][2][cols]
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [kWaves][NACC][cols]
+  constexpr int NACC = DSUM ? 3 : 2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nvec = cols / V;
   const float inv_n = 1.f / static_cast<float>(cols);
 
-  float gam[MAXV][V], dg[MAXV][V], db[MAXV][V];
+  float gam[MAXV][V], dg[MAXV][V], db[MAXV][V], ds[DSUM ? MAXV : 1][V];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int vi = lane + 64 * i;
     if (vi < nvec) load_as_f32<TR, V>(gamma + vi * V, gam[i]);
 #pragma unroll
-    for (int j = 0; j < V; ++j) dg[i][j] = db[i][j] = 0.f;
+    for (int j = 0; j < V; ++j) {
+      dg[i][j] = db[i][j] = 0.f;
+      if (DSUM) ds[i][j] = 0.f;
+    }
   }
 
   for (long long row = static_cast<long long>(blockIdx.x) * kWaves + wid; row < rows; row += static_cast<long long>(gridDim.x) * kWaves) {
@@ -150,13 +163,17 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
 #pragma unroll
           for (int j = 0; j < V; ++j) o[j] += r[j];
         }
+        if (DSUM) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) ds[i][j] += o[j];
+        }
         store_from_f32<TR, V>(dx + row * cols + vi * V, o);
       }
     }
   }
 
   // Combine the workgroup's waves through LDS, then one partial row per workgroup.
-  float* sg = ln_smem + static_cast<size_t>(wid) * 2 * cols;
+  float* sg = ln_smem + static_cast<size_t>(wid) * NACC * cols;
   float* sb = sg + cols;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -166,15 +183,16 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
       for (int j = 0; j < V; ++j) {
         sg[vi * V + j] = dg[i][j];
         sb[vi * V + j] = db[i][j];
+        if (DSUM) sb[cols + vi * V + j] = ds[i][j];
       }
     }
   }
   __syncthreads();
-  float* out = partial + static_cast<size_t>(blockIdx.x) * 2 * cols;
-  for (int c = threadIdx.x; c < 2 * cols; c += kThreads) {
+  float* out = partial + static_cast<size_t>(blockIdx.x) * NACC * cols;
+  for (int c = threadIdx.x; c < NACC * cols; c += kThreads) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) s += ln_smem[static_cast<size_t>(w) * 2 * cols + c];
+    for (int w = 0; w < kWaves; ++w) s += ln_smem[static_cast<size_t>(w) * NACC * cols + c];
     out[c] = s;
   }
 }
@@ -184,13 +202,14 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
 // thread (the kernel is latency-bound: a thread walks nblocks/16 rows), LDS combine.
 template <typename TR>
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, typename TR::T* __restrict__ dgamma,
-                                                                        typename TR::T* __restrict__ dbeta, int cols, int nblocks) {
+                                                                        typename TR::T* __restrict__ dbeta, typename TR::T* __restrict__ dsum,
+                                                                        int cols, int nblocks, int nacc) {
   __shared__ float red[16][17];
   const int cc = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cc;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (c < 2 * cols) {
-    const size_t ld = static_cast<size_t>(2) * cols;
+  if (c < nacc * cols) {
+    const size_t ld = static_cast<size_t>(nacc) * cols;
     int b = rg;
     for (; b + 48 < nblocks; b += 64) {
       s0 += partial[static_cast<size_t>(b) * ld + c];
@@ -202,12 +221,13 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_reduce_kernel(const fl
   }
   red[rg][cc] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rg == 0 && c < 2 * cols) {
+  if (rg == 0 && c < nacc * cols) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cc];
     if (c < cols) dgamma[c] = TR::from_f32(t);
-    else dbeta[c - cols] = TR::from_f32(t);
+    else if (c < 2 * cols) dbeta[c - cols] = TR::from_f32(t);
+    else dsum[c - 2 * cols] = TR::from_f32(t);
   }
 }
 
@@ -230,8 +250,8 @@ bool dispatch_maxv(int need, int limit, F&& f) {
 
 }  // namespace
 
-void launch_layernorm_fwd(const void* x, const void* res, void* sum_out, const void* gamma, const void* beta, void* y, float* mean,
-                          float* rstd, long long rows, long long cols, float eps, int dtype, hipStream_t stream) {
+void launch_layernorm_fwd(const void* x, const void* res, const void* res_bias, void* sum_out, const void* gamma, const void* beta, void* y,
+                          float* mean, float* rstd, long long rows, long long cols, float eps, int dtype, hipStream_t stream) {
   if (rows <= 0) return;
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
@@ -242,31 +262,39 @@ void launch_layernorm_fwd(const void* x, const void* res, void* sum_out, const v
     dispatch_maxv(need, 8, [&](auto mv) {
       constexpr int MAXV = decltype(mv)::value;
       hipLaunchKernelGGL((layernorm_fwd_kernel<TR, MAXV>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream,
-                         static_cast<const T*>(x), static_cast<const T*>(res), static_cast<T*>(sum_out), static_cast<const T*>(gamma),
+                         static_cast<const T*>(x), static_cast<const T*>(res), static_cast<const T*>(res_bias), static_cast<T*>(sum_out),
+                         static_cast<const T*>(gamma),
                          static_cast<const T*>(beta), static_cast<T*>(y), mean, rstd, rows, static_cast<int>(cols), eps);
     });
   });
 }
 
-long long layernorm_bwd_workspace(long long rows, long long cols) { return 2 * cols * pick_blocks(rows); }
+long long layernorm_bwd_workspace(long long rows, long long cols) { return 3 * cols * pick_blocks(rows); }
 
 void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const void* gamma, const float* mean, const float* rstd, void* dx,
-                          void* dgamma, void* dbeta, float* workspace, long long rows, long long cols, int dtype, hipStream_t stream) {
+                          void* dgamma, void* dbeta, void* dsum, float* workspace, long long rows, long long cols, int dtype,
+                          hipStream_t stream) {
   if (rows <= 0) return;
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
     using T = typename TR::T;
     const int need = static_cast<int>((cols / TR::kVec + 63) / 64);
     const int blocks = pick_blocks(rows);
-    const size_t lds = static_cast<size_t>(kWaves) * 2 * cols * sizeof(float);
+    const int nacc = dsum ? 3 : 2;
+    const size_t lds = static_cast<size_t>(kWaves) * nacc * cols * sizeof(float);
     dispatch_maxv(need, 4, [&](auto mv) {
-      constexpr int MAXV = decltype(mv)::value;
-      hipLaunchKernelGGL((layernorm_bwd_kernel<TR, (MAXV > 4 ? 4 : MAXV)>), dim3(blocks), dim3(kThreads), lds, stream,
-                         static_cast<const T*>(dy), static_cast<const T*>(x), static_cast<const T*>(dres), static_cast<const T*>(gamma), mean,
-                         rstd, static_cast<T*>(dx), workspace, rows, static_cast<int>(cols));
+      constexpr int MAXV = decltype(mv)::value > 4 ? 4 : decltype(mv)::value;
+      auto go = [&](auto ds_tag) {
+        constexpr bool DS = decltype(ds_tag)::value;
+        hipLaunchKernelGGL((layernorm_bwd_kernel<TR, MAXV, DS>), dim3(blocks), dim3(kThreads), lds, stream, static_cast<const T*>(dy),
+                           static_cast<const T*>(x), static_cast<const T*>(dres), static_cast<const T*>(gamma), mean, rstd, static_cast<T*>(dx),
+                           workspace, rows, static_cast<int>(cols));
+      };
+      if (dsum) go(std::true_type{});
+      else go(std::false_type{});
     });
-    hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((2 * cols + 15) / 16)), dim3(kThreads),
-                       0, stream, workspace, static_cast<T*>(dgamma), static_cast<T*>(dbeta), static_cast<int>(cols), blocks);
+    hipLaunchKernelGGL((layernorm_bwd_reduce_kernel<TR>), dim3(static_cast<unsigned>((nacc * cols + 15) / 16)), dim3(kThreads), 0, stream,
+                       workspace, static_cast<T*>(dgamma), static_cast<T*>(dbeta), static_cast<T*>(dsum), static_cast<int>(cols), blocks, nacc);
   });
 }
 

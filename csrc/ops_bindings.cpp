@@ -458,7 +458,8 @@ Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tens
 
 // ------------------------------------------------------------------ layer norm
 // y = LN(x) or, with `res`, s = x + res and y = LN(s).  Returns (y, mean, rstd, s); s is x itself without `res`.
-std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor gamma, Tensor beta, double eps, c10::optional<Tensor> res) {
+std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor gamma, Tensor beta, double eps, c10::optional<Tensor> res,
+                                                             c10::optional<Tensor> res_bias) {
   check_gpu(x, "x");
   check_gpu(gamma, "weight");
   check_gpu(beta, "bias");
@@ -480,16 +481,25 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor ga
     sum = at::empty_like(x);
     res_ptr = res->data_ptr();
   }
+  const void* res_bias_ptr = nullptr;
+  if (res_bias.has_value()) {
+    TORCH_CHECK(res.has_value(), "layernorm_forward: res_bias needs res");
+    check_gpu(*res_bias, "res_bias");
+    TORCH_CHECK(res_bias->numel() == cols && res_bias->scalar_type() == x.scalar_type() && res_bias->get_device() == x.get_device(),
+                "layernorm_forward: res_bias must be [cols] of x's dtype");
+    res_bias_ptr = res_bias->data_ptr();
+  }
   auto fopt = x.options().dtype(at::kFloat);
   Tensor mean = at::empty({rows}, fopt), rstd = at::empty({rows}, fopt);
   DevGuard guard(x);
-  kernels::launch_layernorm_fwd(x.data_ptr(), res_ptr, res_ptr ? sum.data_ptr() : nullptr, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+  kernels::launch_layernorm_fwd(x.data_ptr(), res_ptr, res_bias_ptr, res_ptr ? sum.data_ptr() : nullptr, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                 mean.data_ptr<float>(), rstd.data_ptr<float>(), rows, cols, static_cast<float>(eps), kdtype(x), stream_of(x));
   return {y, mean, rstd, sum};
 }
 
-// dx = LN'(dy) + dres (dres optional).
-std::tuple<Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tensor gamma, Tensor mean, Tensor rstd, c10::optional<Tensor> dres) {
+// dx = LN'(dy) + dres (dres optional).  want_dsum: the fourth result is the column sum of dx (else undefined).
+std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tensor gamma, Tensor mean, Tensor rstd, c10::optional<Tensor> dres,
+                                                              bool want_dsum) {
   check_gpu(dy, "dy");
   check_gpu(x, "x");
   check_gpu(gamma, "weight");
@@ -510,12 +520,15 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor x, Tenso
                 "layernorm_backward: dres must match x");
     dres_ptr = dres->data_ptr();
   }
+  TORCH_CHECK(!want_dsum || cols <= 1365, "layernorm_backward: the fused column sum of dx supports at most 1365 columns");
   Tensor dx = at::empty_like(x), dgamma = at::empty_like(gamma), dbeta = at::empty_like(gamma);
+  Tensor dsum = want_dsum ? at::empty_like(gamma) : Tensor();
   Tensor ws = at::empty({kernels::layernorm_bwd_workspace(rows, cols)}, x.options().dtype(at::kFloat));
   DevGuard guard(x);
   kernels::launch_layernorm_bwd(dy.data_ptr(), x.data_ptr(), dres_ptr, gamma.data_ptr(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
-                                dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr<float>(), rows, cols, kdtype(x), stream_of(x));
-  return {dx, dgamma, dbeta};
+                                dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), want_dsum ? dsum.data_ptr() : nullptr, ws.data_ptr<float>(), rows,
+                                cols, kdtype(x), stream_of(x));
+  return {dx, dgamma, dbeta, dsum};
 }
 
 // ------------------------------------------------------------------ attention
@@ -594,9 +607,9 @@ void init_ops(py::module_& m) {
   m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),
         py::arg("act") = 0);
   m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5,
-        py::arg("res") = py::none());
+        py::arg("res") = py::none(), py::arg("res_bias") = py::none());
   m.def("layernorm_backward", &layernorm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"), py::arg("rstd"),
-        py::arg("dres") = py::none());
+        py::arg("dres") = py::none(), py::arg("want_dsum") = false);
   m.attr("ACT_NONE") = static_cast<int>(kernels::kActNone);
   m.attr("ACT_RELU") = static_cast<int>(kernels::kActRelu);
   m.attr("ACT_GELU") = static_cast<int>(kernels::kActGelu);

@@ -69,13 +69,15 @@ class _Proj(nn.Linear):
         self.impl = impl
         self.act = act
 
-    def forward(self, x):
+    def forward(self, x, skip_bias: bool = False):
+        """``skip_bias``: leave the bias out (the caller adds it inside the next fused add + layer norm)."""
+        bias = None if skip_bias else self.bias
         use_native = self.impl == "native" or (self.impl == "auto" and self.act is not None)
         if use_native and x.is_cuda:
-            return linear_bias_act(x, self.weight, self.bias, self.act)
+            return linear_bias_act(x, self.weight, bias, self.act)
         if self.impl in ("library", "auto") and x.is_cuda:
-            return library_linear_bias_act(x, self.weight, self.bias, self.act)
-        y = F.linear(x, self.weight, self.bias)
+            return library_linear_bias_act(x, self.weight, bias, self.act)
+        y = F.linear(x, self.weight, bias)
         if self.act == "gelu":
             y = F.gelu(y)
         elif self.act == "relu":
@@ -92,9 +94,9 @@ class CausalSelfAttention(nn.Module):
         self.c_attn = _Proj(cfg.n_embd, 3 * cfg.n_embd, cfg.bias, cfg.linear_impl)
         self.c_proj = _Proj(cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
 
-    def forward(self, x):
+    def forward(self, x, skip_bias: bool = False):
         y = causal_attention_qkvpacked(self.c_attn(x), self.n_head, impl=self.impl)
-        return self.c_proj(y)
+        return self.c_proj(y, skip_bias)
 
 
 class MLP(nn.Module):
@@ -103,8 +105,8 @@ class MLP(nn.Module):
         self.c_fc = _Proj(cfg.n_embd, 4 * cfg.n_embd, cfg.bias, cfg.linear_impl, act="gelu")
         self.c_proj = _Proj(4 * cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
 
-    def forward(self, x):
-        return self.c_proj(self.c_fc(x))
+    def forward(self, x, skip_bias: bool = False):
+        return self.c_proj(self.c_fc(x), skip_bias)
 
 
 class Block(nn.Module):
@@ -121,14 +123,17 @@ class Block(nn.Module):
         x = x + self.mlp(self.ln_2(x))
         return x
 
-    def forward_deferred(self, x, pending):
+    def forward_deferred(self, x, pending, pending_bias):
         """Same block with every residual add folded into the layer norm that follows it: takes the
-        residual stream ``x`` plus the not-yet-added output ``pending`` of the previous branch and
-        returns the new stream and this block's own pending MLP output."""
-        x, h = self.ln_1.forward_add(x, pending)
-        a = self.attn(h)
-        x, h = self.ln_2.forward_add(x, a)
-        return x, self.mlp(h)
+        residual stream ``x`` plus the not-yet-added output ``pending`` of the previous branch (whose
+        output-projection bias ``pending_bias`` is still to be added as well) and returns the new
+        stream, this block's own pending MLP output and that output's bias.  The projections run
+        without their bias: it is added inside the next add + layer-norm kernel, whose backward
+        also produces the bias gradient, so neither a bias epilogue nor a column-sum pass exists."""
+        x, h = self.ln_1.forward_add(x, pending, pending_bias)
+        a = self.attn(h, skip_bias=True)
+        x, h = self.ln_2.forward_add(x, a, self.attn.c_proj.bias)
+        return x, self.mlp(h, skip_bias=True), self.mlp.c_proj.bias
 
 
 class GPT2(nn.Module):
@@ -172,10 +177,10 @@ class GPT2(nn.Module):
         pos = torch.arange(T, device=idx.device)
         x = self.wte(idx) + self.wpe(pos)
         if self.cfg.native_ops and self.cfg.fuse_add_norm:
-            pending = None
+            pending = pending_bias = None
             for blk in self.h:
-                x, pending = blk.forward_deferred(x, pending)
-            _, x = self.ln_f.forward_add(x, pending)
+                x, pending, pending_bias = blk.forward_deferred(x, pending, pending_bias)
+            _, x = self.ln_f.forward_add(x, pending, pending_bias)
         else:
             for blk in self.h:
                 x = blk(x)

@@ -30,29 +30,33 @@ class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, weight, mean, rstd = ctx.saved_tensors
-        dx, dg, db = _ext.C().layernorm_backward(dy.contiguous(), x2, weight, mean, rstd)
+        dx, dg, db, _ = _ext.C().layernorm_backward(dy.contiguous(), x2, weight, mean, rstd)
         return dx, dg, db, None
 
 
 class _AddLayerNorm(torch.autograd.Function):
-    """(s, y) = (x + r, LN(x + r)) in one pass; the backward folds the gradient that reaches ``s``
-    from its other consumers (the residual stream) into the layer-norm gradient in one pass too.
-    ``x`` and ``r`` receive the same gradient tensor."""
+    """(s, y) = (x + r [+ r_bias], LN(s)) in one pass; the backward folds the gradient that reaches
+    ``s`` from its other consumers (the residual stream) into the layer-norm gradient in one pass
+    too.  ``x`` and ``r`` receive the same gradient tensor; ``r_bias`` (the bias of the layer that
+    produced ``r``, added here instead of in that layer's GEMM) receives its column sums, which the
+    same kernel accumulates next to the layer-norm parameter gradients."""
 
     @staticmethod
-    def forward(ctx, x2, r2, weight, bias, eps: float):
-        y, mean, rstd, s = _ext.C().layernorm_forward(x2, weight, bias, eps, r2)
+    def forward(ctx, x2, r2, r_bias, weight, bias, eps: float):
+        y, mean, rstd, s = _ext.C().layernorm_forward(x2, weight, bias, eps, r2, r_bias)
         ctx.save_for_backward(s, weight, mean, rstd)
+        ctx.has_r_bias = r_bias is not None
         return s, y
 
     @staticmethod
     def backward(ctx, ds, dy):
         s, weight, mean, rstd = ctx.saved_tensors
         if dy is None:  # only the sum was used downstream
-            return ds, ds, None, None, None
+            drb = ds.sum(0) if ctx.has_r_bias else None
+            return ds, ds, drb, None, None, None
         dres = ds.contiguous() if ds is not None else None
-        dx, dg, db = _ext.C().layernorm_backward(dy.contiguous(), s, weight, mean, rstd, dres)
-        return dx, dx, dg, db, None
+        dx, dg, db, drb = _ext.C().layernorm_backward(dy.contiguous(), s, weight, mean, rstd, dres, ctx.has_r_bias)
+        return dx, dx, (drb if ctx.has_r_bias else None), dg, db, None
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -67,21 +71,25 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     return _LayerNorm.apply(x2, weight.contiguous(), bias.contiguous(), eps).reshape(x.shape)
 
 
-def add_layer_norm(x: torch.Tensor, r, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
-    """Returns ``(s, y)`` with ``s = x + r`` and ``y = layer_norm(s)``; ``r`` may be ``None``
-    (then ``s`` is ``x``).  One kernel on the GPU in each direction instead of add + layer norm."""
+def add_layer_norm(x: torch.Tensor, r, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, r_bias=None):
+    """Returns ``(s, y)`` with ``s = x + r (+ r_bias)`` and ``y = layer_norm(s)``; ``r`` may be
+    ``None`` (then ``s`` is ``x``).  One kernel on the GPU in each direction instead of add + layer
+    norm; ``r_bias`` lets the layer that produced ``r`` skip its own bias add and bias-gradient pass."""
     if r is None:
         return x, layer_norm(x, weight, bias, eps)
     cols = x.shape[-1]
+    if r_bias is not None and (not x.is_cuda or cols > 1365 or r_bias.dtype != x.dtype):
+        r = r + r_bias
+        r_bias = None
     need_grad = torch.is_grad_enabled() and (x.requires_grad or r.requires_grad or weight.requires_grad)
     if (bias is None or not _supported(x, cols, need_grad) or weight.dtype != x.dtype or r.dtype != x.dtype
             or r.shape != x.shape or r.device != x.device):
-        s = x + r
+        s = x + (r if r_bias is None else r + r_bias)
         return s, F.layer_norm(s, (cols,), weight, bias, eps)
     x2, r2 = x.reshape(-1, cols), r.reshape(-1, cols)
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
     r2 = r2 if r2.is_contiguous() else r2.contiguous()
-    s, y = _AddLayerNorm.apply(x2, r2, weight.contiguous(), bias.contiguous(), eps)
+    s, y = _AddLayerNorm.apply(x2, r2, None if r_bias is None else r_bias.contiguous(), weight.contiguous(), bias.contiguous(), eps)
     return s.reshape(x.shape), y.reshape(x.shape)
 
 
@@ -93,9 +101,9 @@ class LayerNorm(nn.LayerNorm):
             return super().forward(x)
         return layer_norm(x, self.weight, self.bias, self.eps)
 
-    def forward_add(self, x: torch.Tensor, r):
-        """``(x + r, self(x + r))`` fused; ``r`` may be ``None``."""
+    def forward_add(self, x: torch.Tensor, r, r_bias=None):
+        """``(s, self(s))`` with ``s = x + r (+ r_bias)``, fused; ``r`` may be ``None``."""
         if len(self.normalized_shape) != 1 or self.weight is None:
-            s = x if r is None else x + r
+            s = x if r is None else x + (r if r_bias is None else r + r_bias)
             return s, super().forward(s)
-        return add_layer_norm(x, r, self.weight, self.bias, self.eps)
+        return add_layer_norm(x, r, self.weight, self.bias, self.eps, r_bias)

@@ -546,3 +546,33 @@ def test_projection_cross_entropy_fused_matches_reference(N, K, V, nc, dtype):
     torch.testing.assert_close(xs.grad.double(), xr.grad, **tg)
     torch.testing.assert_close(ws.grad.double(), wr.grad, **tg)
     assert torch.count_nonzero(ws.grad[nc:].float()) == 0  # padding classes get no gradient
+
+
+def test_add_layernorm_with_branch_bias_and_its_gradient():
+    """s = x + r + r_bias in the forward kernel; the backward kernel also returns colsum(ds), the
+    gradient of r_bias, next to dgamma / dbeta."""
+    from distributed_pytorch_amd.ops.layernorm import add_layer_norm
+
+    torch.manual_seed(5)
+    rows, cols = 700, 768
+    x = torch.randn(rows, cols, device=DEV).bfloat16()
+    r = torch.randn(rows, cols, device=DEV).bfloat16()
+    rb = torch.randn(cols, device=DEV).bfloat16()
+    g = torch.randn(cols, device=DEV).bfloat16()
+    b = torch.randn(cols, device=DEV).bfloat16()
+    gs_, gy_ = torch.randn(rows, cols, device=DEV).bfloat16(), torch.randn(rows, cols, device=DEV).bfloat16()
+    xs, rs, rbs, gg, bb = (t.clone().requires_grad_() for t in (x, r, rb, g, b))
+    s, y = add_layer_norm(xs, rs, gg, bb, 1e-5, rbs)
+    torch.autograd.backward([s, y], [gs_, gy_])
+    xr, rr, rbr, gr, br = (t.double().requires_grad_() for t in (x, r, rb, g, b))
+    sr = xr + (rr + rbr)
+    yr = F.layer_norm(sr, (cols,), gr, br, 1e-5)
+    torch.autograd.backward([sr, yr], [gs_.double(), gy_.double()])
+    torch.testing.assert_close(s.double(), sr.detach(), rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(y.double(), yr.detach(), rtol=3e-2, atol=6e-2)
+    torch.testing.assert_close(xs.grad.double(), xr.grad, rtol=4e-2, atol=6e-2)
+    assert torch.equal(xs.grad, rs.grad)
+    scale = math.sqrt(rows)
+    torch.testing.assert_close(rbs.grad.double(), rbr.grad, rtol=3e-2, atol=5e-2 * scale)
+    torch.testing.assert_close(gg.grad.double(), gr.grad, rtol=3e-2, atol=5e-2 * scale)
+    torch.testing.assert_close(bb.grad.double(), br.grad, rtol=3e-2, atol=5e-2 * scale)

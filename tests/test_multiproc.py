@@ -84,11 +84,16 @@ def test_worker_exception_propagates_and_siblings_die(tmp_path):
         dist.launch(mp_workers.crash_worker, str(tmp_path), nprocs=2)
     assert time.time() - t0 < 40
     assert ei.value.rank == 1 and "boom from rank 1" in str(ei.value) and "Traceback" in str(ei.value)
-    time.sleep(0.3)
     for r in range(2):
         pid = int((tmp_path / f"pid{r}").read_text())
-        with pytest.raises(ProcessLookupError):
-            os.kill(pid, 0)  # no orphans
+        deadline = time.time() + 15  # the teardown is asynchronous to the exception on a loaded machine
+        while True:
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                break  # no orphans
+            assert time.time() < deadline, f"rank {r} (pid {pid}) is still alive"
+            time.sleep(0.1)
 
 
 def test_worker_hard_exit_is_reported(tmp_path):

@@ -174,7 +174,12 @@ def test_sigterm_on_launcher_kills_workers(tmp_path):
     pids = [int((tmp_path / f"pid{r}").read_text()) for r in range(2)]
     proc.send_signal(signal.SIGTERM)
     proc.wait(timeout=30)
-    time.sleep(0.5)
     for pid in pids:
-        with pytest.raises(ProcessLookupError):
-            os.kill(pid, 0)
+        deadline = time.time() + 15
+        while True:
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                break
+            assert time.time() < deadline, f"worker {pid} outlived the launcher"
+            time.sleep(0.1)

@@ -451,6 +451,52 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
         *reinterpret_cast<u32x4*>(out + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
       }
     };
+    if (p.aux_mode != kActNone) {
+      // Activation-backward epilogue: C = (alpha*acc) * act'(aux).  The aux tile comes in the way
+      // the result goes out -- 8 rows x 128 contiguous bytes per instruction into the strip, then
+      // each lane picks up the values that sit under its accumulators -- so neither direction
+      // touches global memory with the accumulator layout's 32-byte row pieces.
+      const u16* AUX = static_cast<const u16*>(p.aux);
+      u16* Cout = static_cast<u16*>(p.C);
+      float csum = 0.f;  // lane c: column n0 + wn + c of this wave's 128 rows
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int rl = 8 * it + (lane >> 3), ch = lane & 7;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(AUX + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8);
+          *reinterpret_cast<u32x4*>(mine + rl * kPitch + ch * 16) = v;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            char* cell = mine + (16 * ii + (lane & 15)) * kPitch + (16 * j + 4 * (lane >> 4)) * 2;
+            const u16x4 ax = *reinterpret_cast<const u16x4*>(cell);
+            const f32x4& a = acc[4 * half + ii][j];
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = BF16::to_f32(ax[e]);
+              const float d = p.aux_mode == kActGelu ? gelu_grad(x) : (x > 0.f ? 1.f : 0.f);
+              o[e] = BF16::from_f32(p.alpha * a[e] * d);
+            }
+            *reinterpret_cast<u16x4*>(cell) = o;  // same lane, same cell: read before write by program order
+          }
+        if (p.colsum_partial) {
+#pragma unroll 8
+          for (int rr = 0; rr < 64; ++rr) csum += BF16::to_f32(*reinterpret_cast<const u16*>(mine + rr * kPitch + lane * 2));
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int rl = 8 * it + (lane >> 3), ch = lane & 7;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(mine + rl * kPitch + ch * 16);
+          *reinterpret_cast<u32x4*>(Cout + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
+        }
+      }
+      if (p.colsum_partial) p.colsum_partial[(2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + lane] = csum;
+      return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if (p.pre_act) emit(static_cast<u16*>(p.pre_act), half, false);
@@ -493,6 +539,12 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+bool gemm_bf16_act_backward_supported(const GemmArgs& a) {
+  return gemm_bf16_supported(a) && a.M % BM2 == 0 && a.N % BN2 == 0 && a.K % BK2 == 0 && (a.ldc & 7) == 0 && a.bias == nullptr &&
+         a.pre_act == nullptr && a.beta == 0.f && a.act == kActNone && aligned16(a.C) && aligned16(a.aux) &&
+         (a.aux_mode == kActGelu || a.aux_mode == kActRelu);
+}
+
 int gemm_bf16_split_k(const GemmArgs& a) {
   if (!gemm_bf16_supported(a)) return 1;
   if (a.K % BK2 != 0 || a.N % 4 != 0 || a.M < 8 || a.N < 8) return 1;
@@ -522,7 +574,9 @@ bool gemm_bf16_supported(const GemmArgs& a) {
 
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   const bool split = a.split_k > 1 && a.workspace != nullptr;
-  if (split || use_large_tile(a)) {
+  // the activation-backward epilogue exists in the large-tile kernel only (callers check
+  // gemm_bf16_act_backward_supported first)
+  if (split || use_large_tile(a) || a.aux_mode != kActNone) {
     const int tm2 = static_cast<int>((a.M + BM2 - 1) / BM2), tn2 = static_cast<int>((a.N + BN2 - 1) / BN2);
     const long long nk = a.K / BK2;
     const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);

@@ -108,10 +108,19 @@ struct GemmArgs {
   // gemm_bf16_split_k(); zero / nullptr means a single pass.
   float* workspace;
   int split_k;
+  // Activation-backward epilogue (bf16, 256x256-tile kernel, M and N multiples of 256, no bias /
+  // act / pre_act / beta): C = (alpha*acc) * act'(aux) with aux [M,N] at leading dimension ldc --
+  // the pre-activation for GELU (aux_mode = kActGelu), the activation output for ReLU
+  // (kActRelu).  colsum_partial [2*M/256][N] fp32, when given, receives per-128-row column sums of
+  // the bf16-rounded result (the bias gradient of the layer whose activation this is).
+  const void* aux;
+  int aux_mode;
+  float* colsum_partial;
 };
 // Number of contraction ranges worth using for this product (1 = do not split): > 1 when the
 // output has too few 256x256 tiles to occupy the chip but a long contraction (weight gradients).
 int gemm_bf16_split_k(const GemmArgs& a);
+bool gemm_bf16_act_backward_supported(const GemmArgs& a);
 bool gemm_f32_supported(const GemmArgs& a);
 void launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 bool gemm_bf16_supported(const GemmArgs& a);
@@ -139,6 +148,9 @@ void launch_outer_wgrad(const void* dy, const void* x, void* dw, void* db, float
 //   db[N] = colsum(dy[M,N])  (also used by the large-GEMM path)
 void launch_colsum(const void* dy, void* db, float* workspace, long long M, long long N, int dtype,
                    hipStream_t stream);
+//   out[i] = sum over c < chunks of partial[c][i]   (fixed order)
+void launch_reduce_partials(const float* partial, void* out, long long len, int chunks, int dtype,
+                            hipStream_t stream);
 //   g = dy * act'(saved)  (+ db = colsum(g)); saved = y for ReLU, pre-activation for GELU.
 void launch_act_bwd(const void* dy, const void* saved, void* g, void* db, float* workspace,
                     long long M, long long N, int dtype, int act, hipStream_t stream);

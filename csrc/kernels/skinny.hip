@@ -31,23 +31,6 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// d/dx [x * Phi(x)] = Phi(x) + x * phi(x).  Phi comes from the Abramowitz-Stegun 7.1.26 rational
-// form of erf (absolute error 1.5e-7, fp32-level), which needs exp(-x^2/2) -- the same exponential
-// the density term uses -- so the whole derivative costs one v_exp, one v_rcp and eight FMAs
-// instead of a libm erff call (the backward of the GELU layers is VALU-bound otherwise).
-__device__ __forceinline__ float gelu_grad(float x) {
-  const float ax = fabsf(x);
-  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);  // exp(-x^2/2)
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.f));       // 1 / (1 + p*|x|/sqrt(2)), p = 0.3275911
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float tail = 0.5f * poly * t * e;            // 1 - Phi(|x|)
-  const float cdf = x >= 0.f ? 1.f - tail : tail;
-  return fmaf(x * 0.3989422804014327f, e, cdf);
-}
-
 // ------------------------------------------------------------------ K = 1 forward
 template <typename TR>
 __global__ __launch_bounds__(kThreads) void outer_bias_act_kernel(const typename TR::T* __restrict__ x,
@@ -511,6 +494,15 @@ void launch_outer_wgrad(const void* dy, const void* x, void* dw, void* db, float
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
     col_reduce<TR, kOuterWgrad>(dy, x, nullptr, db, dw, workspace, M, N, 0, stream);
+  });
+}
+
+void launch_reduce_partials(const float* partial, void* out, long long len, int chunks, int dtype, hipStream_t stream) {
+  if (len <= 0) return;
+  dispatch_dtype(dtype, [&](auto tr) {
+    using TR = decltype(tr);
+    hipLaunchKernelGGL((reduce_partials_kernel<TR>), dim3(static_cast<unsigned>((len + 15) / 16)), dim3(kThreads), 0, stream, partial,
+                       static_cast<typename TR::T*>(out), len, chunks);
   });
 }
 

@@ -456,6 +456,45 @@ Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tens
   return C;
 }
 
+// g = (dout @ w) * act'(aux) in one kernel, plus db = colsum(g) when wanted: the input-gradient
+// GEMM of a layer fused with the activation backward of the layer in front of it.
+//   dout [M, K] (gradient of the layer's output), w [K, N] (its weight, as stored: [out, in]),
+//   aux [M, N]: pre-activation (GELU) or activation output (ReLU) of the layer in front.
+std::tuple<Tensor, Tensor> dgrad_act_backward(Tensor dout, Tensor w, Tensor aux, int64_t act, bool want_colsum) {
+  check_gpu(dout, "dout");
+  check_gpu(w, "weight");
+  check_gpu(aux, "aux");
+  TORCH_CHECK(dout.dim() == 2 && w.dim() == 2 && aux.dim() == 2 && dout.size(1) == w.size(0) && aux.size(0) == dout.size(0) &&
+                  aux.size(1) == w.size(1), "dgrad_act_backward: shapes must be dout [M,K], weight [K,N], aux [M,N]");
+  TORCH_CHECK(dout.scalar_type() == at::kBFloat16 && w.scalar_type() == at::kBFloat16 && aux.scalar_type() == at::kBFloat16,
+              "dgrad_act_backward: bf16 tensors expected");
+  TORCH_CHECK(dout.get_device() == w.get_device() && dout.get_device() == aux.get_device(), "dgrad_act_backward: device mismatch");
+  const int64_t M = dout.size(0), K = dout.size(1), N = w.size(1);
+  Tensor g = at::empty({M, N}, dout.options());
+  kernels::GemmArgs a{};
+  a.A = dout.data_ptr(); a.B = w.data_ptr(); a.C = g.data_ptr();
+  a.M = M; a.N = N; a.K = K;
+  a.lda = K; a.ldb = N; a.ldc = N;
+  a.a_kmajor = 1; a.b_kmajor = 0;
+  a.act = kernels::kActNone; a.alpha = 1.f;
+  a.aux = aux.data_ptr(); a.aux_mode = static_cast<int>(act);
+  Tensor partial, db;
+  if (want_colsum) {
+    partial = at::empty({2 * (M / 256), N}, dout.options().dtype(at::kFloat));
+    a.colsum_partial = partial.data_ptr<float>();
+    db = at::empty({N}, dout.options());
+  }
+  TORCH_CHECK(kernels::gemm_bf16_act_backward_supported(a),
+              "dgrad_act_backward: needs M and N multiples of 256, K a multiple of 64, 16-byte aligned tensors, act relu | gelu");
+  DevGuard guard(dout);
+  hipStream_t s = stream_of(dout);
+  kernels::launch_gemm_bf16(a, s);
+  if (want_colsum) kernels::launch_reduce_partials(partial.data_ptr<float>(), db.data_ptr(), N, static_cast<int>(2 * (M / 256)), kernels::kBF16, s);
+  return {g, db};
+}
+
+bool dgrad_act_backward_supported(int64_t M, int64_t N, int64_t K) { return M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && M > 0 && N > 0 && K > 0; }
+
 // ------------------------------------------------------------------ layer norm
 // y = LN(x) or, with `res`, s = x + res and y = LN(s).  Returns (y, mean, rstd, s); s is x itself without `res`.
 std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor gamma, Tensor beta, double eps, c10::optional<Tensor> res,
@@ -585,6 +624,8 @@ void init_ops(py::module_& m) {
     return kernels::gemm_bf16_split_k(a);
   }, "contraction ranges the bf16 GEMM would use for an [M,K]x[K,N] product (1 = single pass)");
   m.def("xent_fused", &xent_fused, py::arg("logits"), py::arg("targets"), py::arg("n_classes"), py::arg("ignore_index"), py::arg("mean"));
+  m.def("dgrad_act_backward", &dgrad_act_backward, py::arg("dout"), py::arg("weight"), py::arg("aux"), py::arg("act"), py::arg("want_colsum"));
+  m.def("dgrad_act_backward_supported", &dgrad_act_backward_supported);
   m.def("attention_supported", [](int64_t T, int64_t hd, int64_t rs) { return kernels::attention_supported(T, hd, rs); });
   m.def("multi_copy_scale", &multi_copy_scale, py::arg("srcs"), py::arg("dsts"), py::arg("scale") = 1.0);
   m.def("scale_inplace", &scale_inplace);

@@ -29,6 +29,7 @@ from ..ops.attention import causal_attention_qkvpacked
 from ..ops.cross_entropy import projection_cross_entropy, softmax_cross_entropy
 from ..ops.layernorm import LayerNorm
 from ..ops.linear import library_linear_bias_act, linear_bias_act
+from ..ops.mlp import fused_mlp
 
 
 @dataclass
@@ -46,6 +47,7 @@ class GPT2Config:
     attention_impl: str = "auto"  # auto | native | sdpa
     fuse_add_norm: bool = True    # fold each residual add into the layer norm that follows it
     fused_lm_head_loss: bool = True  # lm-head GEMM + loss + logits gradient as one autograd node
+    fused_mlp: bool = True        # c_fc -> GELU -> c_proj as one autograd node (fused backward epilogue)
 
     @property
     def padded_vocab_size(self) -> int:
@@ -102,10 +104,15 @@ class CausalSelfAttention(nn.Module):
 class MLP(nn.Module):
     def __init__(self, cfg: GPT2Config):
         super().__init__()
+        self.fused = cfg.fused_mlp and cfg.native_ops and cfg.linear_impl == "library" and cfg.bias
         self.c_fc = _Proj(cfg.n_embd, 4 * cfg.n_embd, cfg.bias, cfg.linear_impl, act="gelu")
         self.c_proj = _Proj(4 * cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
 
     def forward(self, x, skip_bias: bool = False):
+        if self.fused and x.is_cuda:
+            # both layers as one autograd node: the backward fuses GELU' and the c_fc bias gradient into
+            # the epilogue of c_proj's input-gradient GEMM
+            return fused_mlp(x, self.c_fc.weight, self.c_fc.bias, self.c_proj.weight, None if skip_bias else self.c_proj.bias, "gelu")
         return self.c_proj(self.c_fc(x), skip_bias)
 
 

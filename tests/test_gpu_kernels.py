@@ -576,3 +576,39 @@ def test_add_layernorm_with_branch_bias_and_its_gradient():
     torch.testing.assert_close(rbs.grad.double(), rbr.grad, rtol=3e-2, atol=5e-2 * scale)
     torch.testing.assert_close(gg.grad.double(), gr.grad, rtol=3e-2, atol=5e-2 * scale)
     torch.testing.assert_close(bb.grad.double(), br.grad, rtol=3e-2, atol=5e-2 * scale)
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_fused_mlp_matches_reference(act):
+    """c_fc -> act -> c_proj as one node: the backward's fused GEMM epilogue (act' and the bias
+    column sums) against fp64 autograd."""
+    from distributed_pytorch_amd.ops.mlp import fused_mlp, fused_mlp_supported
+
+    torch.manual_seed(11)
+    M, Cin, Hid = 512, 256, 1024
+    x = (torch.randn(M, Cin, device=DEV) * 0.5).bfloat16()
+    w1 = (torch.randn(Hid, Cin, device=DEV) / 16).bfloat16()
+    b1 = (torch.randn(Hid, device=DEV) * 0.1).bfloat16()
+    w2 = (torch.randn(Cin, Hid, device=DEV) / 32).bfloat16()
+    b2 = (torch.randn(Cin, device=DEV) * 0.1).bfloat16()
+    assert fused_mlp_supported(x, w1, b1, w2, act)
+    ts = [t.clone().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    y = fused_mlp(ts[0], ts[1], ts[2], ts[3], ts[4], act)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    tr = [t.double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    pre = tr[0] @ tr[1].t() + tr[2]
+    h = F.gelu(pre) if act == "gelu" else F.relu(pre)
+    yr = h @ tr[3].t() + tr[4]
+    yr.backward(gy.double())
+    torch.testing.assert_close(y.double(), yr.detach(), rtol=3e-2, atol=3e-2)
+    names = ["dx", "dw_fc", "db_fc", "dw_proj", "db_proj"]
+    for n, a, b in zip(names, ts, tr):
+        ref = b.grad
+        err = (a.grad.double() - ref).abs().max().item()
+        assert err <= 3e-2 * ref.abs().max().item() + 1e-2, (n, err, ref.abs().max().item())
+    # shapes that do not fill whole tiles take the unfused path and still agree
+    xs = x[:100].clone().requires_grad_()
+    assert not fused_mlp_supported(xs, w1, b1, w2, act)
+    y2 = fused_mlp(xs, w1, b1, w2, b2, act)
+    torch.testing.assert_close(y2.double(), yr.detach()[:100], rtol=3e-2, atol=3e-2)

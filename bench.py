@@ -43,6 +43,7 @@ def parse_args(argv=None):
     p.add_argument("--linear-impl", default=os.environ.get("BENCH_LINEAR_IMPL", "library"), choices=["auto", "native", "library", "stock"])
     p.add_argument("--attention-impl", default="auto", choices=["auto", "native", "sdpa"], help="GPT-2 attention kernel (ablation)")
     p.add_argument("--no-fused-mlp", action="store_true", help="GPT-2: separate c_fc / GELU / c_proj autograd nodes (ablation)")
+    p.add_argument("--no-fused-qkv-attention", action="store_true", help="GPT-2: c_attn and attention as separate autograd nodes (ablation)")
     p.add_argument("--no-fused-loss", action="store_true", help="GPT-2: separate lm-head GEMM, loss forward and loss backward passes (ablation)")
     p.add_argument("--no-fuse-add-norm", action="store_true", help="GPT-2: separate residual adds and layer norms (ablation)")
     p.add_argument("--reduce-dtype", default=None, choices=["fp32", "bf16"], help="gradient all-reduce dtype")
@@ -75,7 +76,8 @@ def build_workload(args, device):
         cfg = (GPT2Config.small if name == "gpt2" else GPT2Config.medium)(
             block_size=max(T, 1024), linear_impl="stock" if args.stock else args.linear_impl, native_ops=not args.stock,
             attention_impl=args.attention_impl, fuse_add_norm=not args.no_fuse_add_norm,
-            fused_lm_head_loss=not args.no_fused_loss, fused_mlp=not args.no_fused_mlp)
+            fused_lm_head_loss=not args.no_fused_loss, fused_mlp=not args.no_fused_mlp,
+            fused_qkv_attention=not args.no_fused_qkv_attention)
         model = GPT2(cfg).to(device=device, dtype=dtype)
         idx = torch.randint(0, cfg.vocab_size, (B, T), generator=g).to(device)
         tgt = torch.randint(0, cfg.vocab_size, (B, T), generator=g).to(device)

@@ -178,8 +178,10 @@ __device__ __forceinline__ unsigned lds_address(const char* p) {
 // the last tile read.  Row r of the wave goes to out + r * row_stride (elements).
 constexpr int kOutPitch = 144;
 constexpr int kOutStripBytes = 32 * kOutPitch;
+// `colsum`, when given, receives the 64 column sums of the wave's 32 bf16-rounded rows (lane c writes
+// colsum[c]): the piece of a bias gradient that belongs to these rows.
 __device__ __forceinline__ void store_rows_staged(char* strip, const f32x4 (&acc)[2][4], const float (&row_scale)[2], u16* out,
-                                                  long long row_stride, int lane) {
+                                                  long long row_stride, int lane, float* colsum = nullptr) {
   const int g = lane >> 4, li = lane & 15;
 #pragma unroll
   for (int st = 0; st < 2; ++st)
@@ -196,6 +198,12 @@ __device__ __forceinline__ void store_rows_staged(char* strip, const f32x4 (&acc
     const int r = 8 * it + (lane >> 3), ch = lane & 7;
     const u32x4 v = *reinterpret_cast<const u32x4*>(strip + r * kOutPitch + ch * 16);
     *reinterpret_cast<u32x4*>(out + r * row_stride + ch * 8) = v;
+  }
+  if (colsum) {
+    float cs = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) cs += BF16::to_f32(*reinterpret_cast<const u16*>(strip + r * kOutPitch + lane * 2));
+    colsum[lane] = cs;
   }
 }
 
@@ -399,6 +407,7 @@ struct AttnBwdParams {
   const float* lse;   // [B, H, T]
   float* delta;       // [B, H, T]: sum_d dO*O, written by the dQ kernel and read by the dK/dV kernel
   float* lse2;        // [B, H, T]: lse * log2(e), likewise
+  float* bias_partial;  // nullptr, or [B*T/32][3*H*64]: column sums of dq | dk | dv per block of 32 positions
   u16* dq;            // gradient tensors use grad_row_stride between consecutive t
   u16* dk;
   u16* dv;
@@ -548,8 +557,10 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams 
   }
   __syncthreads();  // tile stages -> output strips
   const float one[2] = {1.f, 1.f};
+  const long long C3 = 3LL * p.H * HD;
+  float* bq = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + q0) >> 5) * C3 + static_cast<long long>(h) * HD : nullptr;
   store_rows_staged(smem + wid * kOutStripBytes, dq, one,
-                    p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD, p.grad_row_stride, lane);
+                    p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD, p.grad_row_stride, lane, bq);
 }
 
 constexpr int BQT = 64;                          // queries per LDS stage in the dK/dV kernel (two 32-query halves)
@@ -721,8 +732,11 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParam
   __syncthreads();  // tile stages -> output strips
   const float one[2] = {1.f, 1.f};
   const long long out_off = (static_cast<long long>(b) * p.T + k0w) * p.grad_row_stride + static_cast<long long>(h) * HD;
-  store_rows_staged(smem + wid * kOutStripBytes, dk, one, p.dk + out_off, p.grad_row_stride, lane);
-  store_rows_staged(smem + wid * kOutStripBytes, dv, one, p.dv + out_off, p.grad_row_stride, lane);
+  const long long C3 = 3LL * p.H * HD;
+  float* bk = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + k0w) >> 5) * C3 + (p.H + h) * static_cast<long long>(HD) : nullptr;
+  float* bvp = bk ? bk + static_cast<long long>(p.H) * HD : nullptr;
+  store_rows_staged(smem + wid * kOutStripBytes, dk, one, p.dk + out_off, p.grad_row_stride, lane, bk);
+  store_rows_staged(smem + wid * kOutStripBytes, dv, one, p.dv + out_off, p.grad_row_stride, lane, bvp);
 }
 
 }  // namespace
@@ -747,7 +761,7 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
 
 void launch_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, long long row_stride, long long grad_row_stride, int B, int H, int T,
-                          float softmax_scale, hipStream_t stream) {
+                          float softmax_scale, float* bias_partial, hipStream_t stream) {
   AttnBwdParams p;
   p.o = static_cast<const u16*>(o);
   p.q = static_cast<const u16*>(q);
@@ -757,6 +771,7 @@ void launch_attention_bwd(const void* q, const void* k, const void* v, const voi
   p.lse = lse;
   p.delta = delta;  // workspace of 2*B*H*T floats: delta, then lse in the log2 domain
   p.lse2 = delta + static_cast<long long>(B) * H * T;
+  p.bias_partial = bias_partial;
   p.dq = static_cast<u16*>(dq);
   p.dk = static_cast<u16*>(dk);
   p.dv = static_cast<u16*>(dv);

@@ -180,7 +180,9 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
 void launch_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                           const float* lse, float* delta, void* dq, void* dk, void* dv,
                           long long row_stride, long long grad_row_stride, int B, int H, int T,
-                          float softmax_scale, hipStream_t stream);
+                          float softmax_scale, float* bias_partial, hipStream_t stream);
+// bias_partial: nullptr, or [B*T/32][3*H*64] fp32 receiving the column sums of dq | dk | dv per block
+// of 32 positions (summed over the first index they give the bias gradient of the q|k|v projection).
 
 }  // namespace kernels
 }  // namespace dpa

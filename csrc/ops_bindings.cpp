@@ -588,8 +588,9 @@ std::tuple<Tensor, Tensor> attention_forward(Tensor qkv, int64_t n_head, double 
   return {o, lse};
 }
 
-// Returns dqkv [B, T, 3*C] given the forward's inputs / outputs and do [B, T, C].
-Tensor attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t n_head, double softmax_scale) {
+// Returns (dqkv [B, T, 3*C], dbias [3*C] or undefined) given the forward's inputs / outputs and do [B, T, C].
+// want_bias_grad: the kernels also emit the column sums of dqkv (gradient of the projection's bias).
+std::tuple<Tensor, Tensor> attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t n_head, double softmax_scale, bool want_bias_grad) {
   check_gpu(d_o, "do");
   check_gpu(qkv, "qkv");
   check_gpu(o, "o");
@@ -600,22 +601,31 @@ Tensor attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t 
   TORCH_CHECK(d_o.sizes() == o.sizes() && o.size(0) == B && o.size(1) == T && o.size(2) == Cd, "attention_backward: shape mismatch");
   TORCH_CHECK(lse.scalar_type() == at::kFloat && lse.numel() == B * n_head * T, "attention_backward: lse must be float32 [B, H, T]");
   TORCH_CHECK(kernels::attention_supported(T, hd, C3), "attention_backward: unsupported shape");
+  TORCH_CHECK(d_o.is_contiguous() && qkv.is_contiguous() && o.is_contiguous() && lse.is_contiguous(), "attention_backward: contiguous tensors expected");
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty({2, B, n_head, T}, lse.options());  // delta | lse*log2(e), filled by the dQ kernel
+  Tensor partial, dbias;
+  if (want_bias_grad) {
+    partial = at::empty({B * T / 32, C3}, lse.options());
+    dbias = at::empty({C3}, qkv.options());
+  }
   DevGuard guard(qkv);
+  hipStream_t s = stream_of(qkv);
   const char* base = static_cast<const char*>(qkv.data_ptr());
   char* gbase = static_cast<char*>(dqkv.data_ptr());
   kernels::launch_attention_bwd(base, base + Cd * 2, base + 2 * Cd * 2, o.data_ptr(), d_o.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(),
                                 gbase, gbase + Cd * 2, gbase + 2 * Cd * 2, C3, C3, static_cast<int>(B), static_cast<int>(n_head),
-                                static_cast<int>(T), static_cast<float>(softmax_scale), stream_of(qkv));
-  return dqkv;
+                                static_cast<int>(T), static_cast<float>(softmax_scale), want_bias_grad ? partial.data_ptr<float>() : nullptr, s);
+  if (want_bias_grad) kernels::launch_reduce_partials(partial.data_ptr<float>(), dbias.data_ptr(), C3, static_cast<int>(B * T / 32), kernels::kBF16, s);
+  return {dqkv, dbias};
 }
 
 }  // namespace
 
 void init_ops(py::module_& m) {
   m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("n_head"), py::arg("softmax_scale"));
-  m.def("attention_backward", &attention_backward);
+  m.def("attention_backward", &attention_backward, py::arg("do"), py::arg("qkv"), py::arg("o"), py::arg("lse"), py::arg("n_head"),
+        py::arg("softmax_scale"), py::arg("want_bias_grad") = false);
   m.def("gemm_bf16_split_k", [](int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor) {
     kernels::GemmArgs a{};
     a.M = M; a.N = N; a.K = K;

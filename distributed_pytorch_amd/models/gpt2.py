@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops.attention import causal_attention_qkvpacked
+from ..ops.attention import causal_attention_qkvpacked, projected_causal_attention
 from ..ops.cross_entropy import projection_cross_entropy, softmax_cross_entropy
 from ..ops.layernorm import LayerNorm
 from ..ops.linear import library_linear_bias_act, linear_bias_act
@@ -48,6 +48,7 @@ class GPT2Config:
     fuse_add_norm: bool = True    # fold each residual add into the layer norm that follows it
     fused_lm_head_loss: bool = True  # lm-head GEMM + loss + logits gradient as one autograd node
     fused_mlp: bool = True        # c_fc -> GELU -> c_proj as one autograd node (fused backward epilogue)
+    fused_qkv_attention: bool = True  # c_attn + attention as one node (bias gradient out of the attention backward)
 
     @property
     def padded_vocab_size(self) -> int:
@@ -93,11 +94,14 @@ class CausalSelfAttention(nn.Module):
         assert cfg.n_embd % cfg.n_head == 0
         self.n_head = cfg.n_head
         self.impl = cfg.attention_impl if cfg.native_ops else "sdpa"
+        self.fused = cfg.fused_qkv_attention and cfg.native_ops and cfg.linear_impl == "library" and cfg.bias and self.impl != "sdpa"
         self.c_attn = _Proj(cfg.n_embd, 3 * cfg.n_embd, cfg.bias, cfg.linear_impl)
         self.c_proj = _Proj(cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
 
     def forward(self, x, skip_bias: bool = False):
-        y = causal_attention_qkvpacked(self.c_attn(x), self.n_head, impl=self.impl)
+        y = projected_causal_attention(x, self.c_attn.weight, self.c_attn.bias, self.n_head) if self.fused else None
+        if y is None:
+            y = causal_attention_qkvpacked(self.c_attn(x), self.n_head, impl=self.impl)
         return self.c_proj(y, skip_bias)
 
 

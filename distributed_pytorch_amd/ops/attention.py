@@ -38,7 +38,32 @@ class _FlashQKV(torch.autograd.Function):
     def backward(ctx, d_o):
         qkv, o, lse = ctx.saved_tensors
         d_o = d_o if d_o.is_contiguous() else d_o.contiguous()
-        return _ext.C().attention_backward(d_o, qkv, o, lse, ctx.n_head, ctx.scale), None, None
+        return _ext.C().attention_backward(d_o, qkv, o, lse, ctx.n_head, ctx.scale)[0], None, None
+
+
+class _ProjFlashQKV(torch.autograd.Function):
+    """q|k|v projection + attention as one node: the attention backward kernels sum their dq / dk / dv
+    tiles over the rows on the way out, which is the projection's bias gradient, so the [tokens, 3*C]
+    gradient is not re-read by a column-sum pass."""
+
+    @staticmethod
+    def forward(ctx, x2, w, b, B, T, n_head, scale):
+        qkv = F.linear(x2, w, b).view(B, T, w.shape[0])
+        o, lse = _ext.C().attention_forward(qkv, n_head, scale)
+        ctx.save_for_backward(x2, w, qkv, o, lse)
+        ctx.n_head, ctx.scale = n_head, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        from .mlp import _wgrad
+        C = _ext.C()
+        x2, w, qkv, o, lse = ctx.saved_tensors
+        d_o = d_o if d_o.is_contiguous() else d_o.contiguous()
+        dqkv, db = C.attention_backward(d_o, qkv, o, lse, ctx.n_head, ctx.scale, True)
+        g = dqkv.view(-1, dqkv.shape[-1])
+        dx = g @ w if ctx.needs_input_grad[0] else None
+        return dx, _wgrad(C, g, x2), db, None, None, None, None
 
 
 def native_attention_supported(qkv: torch.Tensor, n_head: int) -> bool:
@@ -50,6 +75,24 @@ def native_attention_supported(qkv: torch.Tensor, n_head: int) -> bool:
     if C3 % (3 * n_head):
         return False
     return bool(_ext.C().attention_supported(T, C3 // 3 // n_head, C3))
+
+
+def projected_causal_attention(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], n_head: int,
+                               softmax_scale: Optional[float] = None) -> Optional[torch.Tensor]:
+    """``attention(x @ weight.T + bias)`` for x [B, T, C_in] and a [3*C, C_in] q|k|v projection, as one
+    autograd node on the native kernels.  Returns None when the shape / dtype is not covered (the
+    caller then runs the projection and ``causal_attention_qkvpacked`` separately)."""
+    if bias is None or x.dim() != 3 or not (x.is_cuda and x.dtype == weight.dtype == torch.bfloat16) or not _ext.have_C():
+        return None
+    B, T, _ = x.shape
+    C3 = weight.shape[0]
+    if C3 % (3 * n_head) or not _ext.C().attention_supported(T, C3 // 3 // n_head, C3) or (B * T) % 32:
+        return None
+    hd = C3 // 3 // n_head
+    scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(hd)
+    x2 = x.reshape(B * T, x.shape[-1])
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    return _ProjFlashQKV.apply(x2, weight, bias, B, T, n_head, scale)
 
 
 def causal_attention_qkvpacked(qkv: torch.Tensor, n_head: int, softmax_scale: Optional[float] = None,

@@ -399,7 +399,7 @@ def test_flash_attention_forward_backward(B, T, H):
     torch.testing.assert_close(lse, ref_lse, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(o.float(), ref_o, rtol=2e-2, atol=2e-2)
     go = torch.randn_like(o)
-    dqkv = C().attention_backward(go, qkv, o, lse, H, scale)
+    dqkv, _ = C().attention_backward(go, qkv, o, lse, H, scale)
     ref_o.backward(go.float())
     ref_g = torch.cat([t.grad.transpose(1, 2).reshape(B, T, Cd) for t in (q, k, v)], dim=2)
     # bf16 P / dS operands and bf16 outputs: error scales with the gradient magnitude
@@ -426,8 +426,48 @@ def test_flash_attention_large_logits_and_causality():
     assert torch.equal(o[:, :130], o2[:, :130])
     g = torch.zeros_like(o)
     g[:, :130] = 1
-    d = C().attention_backward(g, qkv, o, lse, H, scale)
+    d, _ = C().attention_backward(g, qkv, o, lse, H, scale)
     assert torch.count_nonzero(d[:, 130:].float()) == 0  # no gradient flows to later positions
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 384, 3), (4, 1024, 12)])
+def test_attention_backward_bias_gradient(B, T, H):
+    """The column sums the backward kernels emit equal the sum over positions of the dqkv they wrote."""
+    torch.manual_seed(T + H)
+    Cd = H * 64
+    qkv = torch.randn(B, T, 3 * Cd, device=DEV).bfloat16()
+    scale = 1.0 / math.sqrt(64)
+    o, lse = C().attention_forward(qkv, H, scale)
+    go = torch.randn_like(o)
+    dqkv, db = C().attention_backward(go, qkv, o, lse, H, scale, True)
+    plain, none = C().attention_backward(go, qkv, o, lse, H, scale)
+    assert none is None and torch.equal(dqkv, plain)
+    ref = dqkv.float().sum((0, 1))
+    assert db.shape == (3 * Cd,) and db.dtype == torch.bfloat16
+    torch.testing.assert_close(db.float(), ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item())
+
+
+def test_projected_attention_matches_separate_nodes():
+    from distributed_pytorch_amd.ops.attention import causal_attention_qkvpacked, projected_causal_attention
+
+    torch.manual_seed(11)
+    B, T, H, Cin = 2, 256, 4, 256
+    x = torch.randn(B, T, Cin, device=DEV).bfloat16().requires_grad_()
+    w = (torch.randn(3 * H * 64, Cin, device=DEV) * 0.05).bfloat16().requires_grad_()
+    b = (torch.randn(3 * H * 64, device=DEV) * 0.1).bfloat16().requires_grad_()
+    y = projected_causal_attention(x, w, b, H)
+    assert y is not None
+    g = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), g)
+    xr, wr, br = (t.detach().float().requires_grad_() for t in (x, w, b))
+    yr = causal_attention_qkvpacked(torch.nn.functional.linear(xr, wr, br), H, impl="sdpa")
+    rx, rw, rb = torch.autograd.grad(yr, (xr, wr, br), g.float())
+    torch.testing.assert_close(y.float(), yr, rtol=3e-2, atol=3e-2)
+    for got, ref in ((gx, rx), (gw, rw), (gb, rb)):
+        assert (got.float() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item() + 1e-2
+    # not covered -> None, the caller takes the two-node path
+    assert projected_causal_attention(x[:, :100], w, b, H) is None
+    assert projected_causal_attention(x, w, None, H) is None
 
 
 def test_attention_op_autograd_and_fallback():

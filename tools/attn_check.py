@@ -20,7 +20,7 @@ ref_lse = torch.logsumexp(s.masked_fill(~mask, float("-inf")), -1)
 print("fwd max err", (o.float() - ref_o).abs().max().item(), "lse err", (lse - ref_lse).abs().max().item())
 if do_bwd:
     go = torch.randn_like(o)
-    dqkv = C.attention_backward(go, qkv, o, lse, H, scale)
+    dqkv, _ = C.attention_backward(go, qkv, o, lse, H, scale)
     ref_o.backward(go.float())
     rg = torch.cat([t.grad.transpose(1, 2).reshape(B, T, Cd) for t in (q, k, v)], dim=2)
     for name, a, b in zip("qkv", dqkv.float().split(Cd, 2), rg.split(Cd, 2)):

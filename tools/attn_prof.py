@@ -8,5 +8,5 @@ qkv = torch.randn(B, T, 3 * H * 64, device="cuda").bfloat16()
 scale = 1.0 / math.sqrt(64)
 for _ in range(3):
     o, lse = C.attention_forward(qkv, H, scale)
-    d = C.attention_backward(torch.ones_like(o), qkv, o, lse, H, scale)
+    d, _ = C.attention_backward(torch.ones_like(o), qkv, o, lse, H, scale)
 torch.cuda.synchronize()

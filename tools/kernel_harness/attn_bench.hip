@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   const long long Cd = H * 64;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto fwd = [&] { dpa::kernels::launch_attention_fwd(qkv, qkv + Cd, qkv + 2 * Cd, o, lse, C3, B, H, T, 0.125f, 0); };
-  auto bwd = [&] { dpa::kernels::launch_attention_bwd(qkv, qkv + Cd, qkv + 2 * Cd, o, d_o, lse, delta, dqkv, dqkv + Cd, dqkv + 2 * Cd, C3, C3, B, H, T, 0.125f, 0); };
+  auto bwd = [&] { dpa::kernels::launch_attention_bwd(qkv, qkv + Cd, qkv + 2 * Cd, o, d_o, lse, delta, dqkv, dqkv + Cd, dqkv + 2 * Cd, C3, C3, B, H, T, 0.125f, nullptr, 0); };
   for (int i = 0; i < 3; ++i) { fwd(); bwd(); }
   float ms;
   hipEventRecord(e0); for (int i = 0; i < 20; ++i) fwd(); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);

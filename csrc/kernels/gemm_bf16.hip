@@ -39,7 +39,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == kActRelu) return v > 0.f ? v : 0.f;
-  if (act == kActGelu) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  if (act == kActGelu) return gelu_fwd(v);
   return v;
 }
 
@@ -231,6 +231,15 @@ __device__ __forceinline__ int kmajor2_off(int row, int c) { return row * 128 + 
 // [64 k][256 rows] image, 512-byte rows, 32 chunks: XOR on the low four chunk bits.
 __device__ __forceinline__ int rmajor2_off(int k, int c) { return k * 512 + ((c ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)))) << 4); }
 
+// GELU'(x) of a bf16 x only takes 65536 values, and outside 2^-12 <= |x| < 8 it is 0.5, 0 or 1 to well
+// below bf16 resolution: the activation-backward epilogue looks the derivative up in an LDS table
+// (15 binades x 128 mantissas per sign, fp32 entries computed by the workgroup itself while its first
+// tile is in flight) instead of evaluating exp / rcp / eight FMAs per element -- with one workgroup per
+// CU nothing overlaps the epilogue's VALU work, which used to take as long as nine k-steps.
+constexpr int kGeluLo = 0x3980;     // bf16 bits of 2^-12
+constexpr int kGeluEntries = 1920;  // up to 0x40FF = 7.97
+constexpr int kGeluTableBytes = 2 * kGeluEntries * 4;
+
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
@@ -269,7 +278,17 @@ __device__ __forceinline__ const char* dma_base(const u16* base, long long ld, l
 // LDS-DMA it knows about (the transposing reads always) behind s_waitcnt vmcnt(0), which would put
 // the whole DMA of tile k+1 in front of the math of tile k.  The kernel orders DMA and reads itself
 // (explicit vmcnt wait + barrier).  The hardware adds lane * 16 to the LDS address in M0.
-__device__ __forceinline__ void dma_issue(const char* base, const unsigned (&off)[4], char* lds_tile, int wid) {
+// The tile base is wave-uniform by construction; the explicit scalarisation keeps it in SGPRs even when
+// the compiler evaluates the 64-bit address arithmetic on the vector ALU (the "s" constraint of the
+// assembly below does not convert by itself).
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __forceinline__ void dma_issue(const char* base_in, const unsigned (&off)[4], char* lds_tile, int wid) {
+  const char* base = uniform_ptr(base_in);
   const unsigned dst0 = __builtin_amdgcn_readfirstlane(
       static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)(lds_tile + wid * 4096))));
 #pragma unroll
@@ -301,7 +320,17 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int tile_row0, int
 // p.workspace[blockIdx.y][M][N] (16-byte stores) and splitk_reduce_kernel finishes the product.
 template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT>
 __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters) {
-  extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 stages][A tile | B tile]
+  extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 stages][A tile | B tile][GELU' table]
+
+  float* gelu_tab = reinterpret_cast<float*>(smem2 + 4 * kTileBytes2);
+  if (!SPLIT && p.aux_mode == kActGelu) {
+    for (int e = threadIdx.x; e < 2 * kGeluEntries; e += kThreads2) {
+      const bool neg = e >= kGeluEntries;
+      const unsigned bits = static_cast<unsigned>(kGeluLo + (neg ? e - kGeluEntries : e)) | (neg ? 0x8000u : 0u);
+      gelu_tab[e] = gelu_grad(__uint_as_float(bits << 16));
+    }
+    __syncthreads();
+  }
 
   const int nwg = tiles_m * tiles_n;
   const int orig = blockIdx.x;
@@ -374,12 +403,33 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // Activation-backward epilogue only: the aux tile is fetched by LDS-DMA as well, each wave's 128 x 64
+  // piece in two halves of 64 rows x 128 B (8 KiB, 8 instructions) at  stage * 64 KiB + wave * 8 KiB.
+  // The first half goes into the stage that the last k-step leaves idle, so its latency hides behind
+  // that step's MFMAs; the second half follows once the operand stages are dead.  LDS position
+  // (lane & 7) of row (lane >> 3) receives chunk (lane & 7) ^ (lane >> 3) of the row (XOR on the
+  // source address), which spreads the accumulator-layout reads of the epilogue over the banks.
+  const bool act_bwd = !SPLIT && p.aux_mode != kActNone;
+  const unsigned aux_off = static_cast<unsigned>(((lane >> 3) * p.ldc + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+  auto aux_request = [&](int half, int stage) __attribute__((always_inline)) {
+    const char* src = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.aux) + (m0 + wm + 64 * half) * p.ldc + n0 + wn));
+    const unsigned dst0 = __builtin_amdgcn_readfirstlane(
+        static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)(smem2 + stage * 2 * kTileBytes2 + wid * 8192))));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const char* base = uniform_ptr(src + it * 16 * p.ldc);  // 8 rows further
+      const unsigned dst = dst0 + it * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(aux_off), "s"(base), "s"(dst) : "memory");
+    }
+  };
+
   request(kt0, 0);
   for (long long kt = kt0; kt < nk; ++kt) {
     const int cur = static_cast<int>((kt - kt0) & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     phase_barrier();
     if (kt + 1 < nk) request(kt + 1, cur ^ 1);
+    else if (act_bwd) aux_request(0, cur ^ 1);
     read_frags(cur);
     __builtin_amdgcn_sched_barrier(0);
     multiply();
@@ -427,8 +477,11 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
         for (int e = 0; e < 4; ++e) bv[j][e] = BF16::to_f32(b4[e]);
       }
     }
-    // one pass per output tensor: the pre-activation (when the backward will need it), then the result
-    auto emit = [&](u16* out, int half, bool activate) {
+    // one pass per output tensor: the pre-activation (when the backward will need it), then the result.
+    // The activation is a compile-time parameter: selected per element it costs a scalar branch for each
+    // of the 128 values a lane owns, more than the arithmetic.
+    auto emit = [&](u16* out, int half, auto act_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -437,9 +490,9 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
           u16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            // the pre-activation is rounded to bf16 first, exactly as the unfused path stores and re-reads it
-            const float v = BF16::to_f32(BF16::from_f32(p.alpha * a[e] + bv[j][e]));
-            o[e] = BF16::from_f32(activate ? act_fn(v, p.act) : v);
+            o[e] = BF16::from_f32(p.alpha * a[e] + bv[j][e]);
+            // the activation sees the pre-activation rounded to bf16, exactly as the unfused path stores and re-reads it
+            if (ACT != kActNone) o[e] = BF16::from_f32(act_fn(BF16::to_f32(o[e]), ACT));
           }
           *reinterpret_cast<u16x4*>(mine + (16 * ii + (lane & 15)) * kPitch + (16 * j + 4 * (lane >> 4)) * 2) = o;
         }
@@ -451,57 +504,79 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
         *reinterpret_cast<u32x4*>(out + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
       }
     };
-    if (p.aux_mode != kActNone) {
-      // Activation-backward epilogue: C = (alpha*acc) * act'(aux).  The aux tile comes in the way
-      // the result goes out -- 8 rows x 128 contiguous bytes per instruction into the strip, then
-      // each lane picks up the values that sit under its accumulators -- so neither direction
-      // touches global memory with the accumulator layout's 32-byte row pieces.
-      const u16* AUX = static_cast<const u16*>(p.aux);
+    if (act_bwd) {
+      // Activation-backward epilogue: C = (alpha*acc) * act'(aux).  Each lane picks the aux values
+      // that sit under its accumulators out of the DMA image, writes the result back into the same
+      // cells, and the rows then leave as 8 rows x 128 contiguous bytes per store instruction -- so
+      // neither direction touches global memory with the accumulator layout's 32-byte row pieces.
+      const int last = static_cast<int>((nk - 1 - kt0) & 1);  // stage of the last k-step; half 0 sits in the other one
+      aux_request(1, last);
       u16* Cout = static_cast<u16*>(p.C);
       float csum = 0.f;  // lane c: column n0 + wn + c of this wave's 128 rows
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int rl = 8 * it + (lane >> 3), ch = lane & 7;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(AUX + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8);
-          *reinterpret_cast<u32x4*>(mine + rl * kPitch + ch * 16) = v;
-        }
+      const int r = lane & 15, g = lane >> 4;
+      const bool gelu = p.aux_mode == kActGelu;
+      auto process = [&](int half, char* img) __attribute__((always_inline)) {
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            char* cell = mine + (16 * ii + (lane & 15)) * kPitch + (16 * j + 4 * (lane >> 4)) * 2;
+            char* cell = img + (16 * ii + r) * 128 + (((2 * j + (g >> 1)) ^ (r & 7)) << 4) + 8 * (g & 1);
             const u16x4 ax = *reinterpret_cast<const u16x4*>(cell);
             const f32x4& a = acc[4 * half + ii][j];
+            float d[4];
+            if (gelu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int bits = ax[e];
+                int idx = (bits & 0x7fff) - kGeluLo;
+                idx = idx < 0 ? 0 : (idx > kGeluEntries - 1 ? kGeluEntries - 1 : idx);  // non-finite inputs land on 0 / 1
+                d[e] = gelu_tab[idx + (bits >> 15) * kGeluEntries];
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[e] = (ax[e] & 0x8000) || !(ax[e] & 0x7fff) ? 0.f : 1.f;
+            }
             u16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = BF16::to_f32(ax[e]);
-              const float d = p.aux_mode == kActGelu ? gelu_grad(x) : (x > 0.f ? 1.f : 0.f);
-              o[e] = BF16::from_f32(p.alpha * a[e] * d);
-            }
+            for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(p.alpha * a[e] * d[e]);
             *reinterpret_cast<u16x4*>(cell) = o;  // same lane, same cell: read before write by program order
           }
         if (p.colsum_partial) {
 #pragma unroll 8
-          for (int rr = 0; rr < 64; ++rr) csum += BF16::to_f32(*reinterpret_cast<const u16*>(mine + rr * kPitch + lane * 2));
+          for (int rr = 0; rr < 64; ++rr)
+            csum += BF16::to_f32(*reinterpret_cast<const u16*>(img + rr * 128 + (((lane >> 3) ^ (rr & 7)) << 4) + (lane & 7) * 2));
         }
+      };
+      auto store_rows = [&](int half, const char* img) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-          const int rl = 8 * it + (lane >> 3), ch = lane & 7;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(mine + rl * kPitch + ch * 16);
+          const int rl = 8 * it + (lane >> 3), ch = (lane & 7) ^ (lane >> 3);
+          const u32x4 v = *reinterpret_cast<const u32x4*>(img + rl * 128 + (lane & 7) * 16);
           *reinterpret_cast<u32x4*>(Cout + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
         }
-      }
+      };
+      char* img0 = smem2 + (last ^ 1) * 2 * kTileBytes2 + wid * 8192;
+      char* img1 = smem2 + last * 2 * kTileBytes2 + wid * 8192;
+      // a wave only ever touches its own two images, and the DMA counts as complete once its data is in LDS
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      process(0, img0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // before any store is in flight: the second half has landed
+      store_rows(0, img0);
+      process(1, img1);
+      store_rows(1, img1);
       if (p.colsum_partial) p.colsum_partial[(2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + lane] = csum;
       return;
     }
+    auto emit_all = [&](auto act_c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (p.pre_act) emit(static_cast<u16*>(p.pre_act), half, false);
-      emit(static_cast<u16*>(p.C), half, true);
-    }
+      for (int half = 0; half < 2; ++half) {
+        if (p.pre_act) emit(static_cast<u16*>(p.pre_act), half, std::integral_constant<int, kActNone>{});
+        emit(static_cast<u16*>(p.C), half, act_c);
+      }
+    };
+    if (p.act == kActGelu) emit_all(std::integral_constant<int, kActGelu>{});
+    else if (p.act == kActRelu) emit_all(std::integral_constant<int, kActRelu>{});
+    else emit_all(std::integral_constant<int, kActNone>{});
     return;
   }
 #pragma unroll
@@ -581,15 +656,16 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
     const long long nk = a.K / BK2;
     const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);
     const dim3 grid2(static_cast<unsigned>(tm2) * static_cast<unsigned>(tn2), split ? static_cast<unsigned>(a.split_k) : 1u);
-    const size_t lds2 = 4 * kTileBytes2;  // 128 KiB: above the 64 KiB default, so the limit is raised per kernel
+    // 128 KiB (+ the GELU' table): above the 64 KiB default, so the limit is raised per kernel
+    const size_t lds2 = 4 * kTileBytes2 + (split ? 0 : kGeluTableBytes);
     auto go2 = [&](auto ak, auto bk) {
       constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
       static bool configured = false;
       if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes2 + kGeluTableBytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes2 + kGeluTableBytes);
         configured = true;
       }
       if (split) {

@@ -34,7 +34,7 @@ constexpr int kTileFloats = BM * BK;  // 4096 floats = 16 KiB per operand per st
 
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == kActRelu) return v > 0.f ? v : 0.f;
-  if (act == kActGelu) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  if (act == kActGelu) return gelu_fwd(v);
   return v;
 }
 

@@ -17,6 +17,7 @@ of ``fc`` in its epilogue and accumulates ``fc``'s bias gradient on the way out,
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -24,6 +25,12 @@ import torch.nn.functional as F
 
 from .. import _ext
 from .linear import ACT_GELU, ACT_RELU, _act_code, _torch_act, library_linear_bias_act
+
+
+# Forward of the first layer with a GELU: native MFMA GEMM with bias + GELU in the epilogue and both the
+# activation and the pre-activation as outputs (True), or vendor GEMM followed by an elementwise pass (False).
+# Measured on GPT-2 small, batch 256: 979 vs 982 samples/s, so the vendor GEMM stays the default.
+NATIVE_FC_FORWARD = os.environ.get("DIST_MLP_NATIVE_FC", "0") == "1"
 
 
 def _wgrad(C, g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -36,8 +43,12 @@ def _wgrad(C, g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, w_fc, b_fc, w_proj, b_proj, act: int):
-        pre = F.linear(x2, w_fc, b_fc)
-        h = _torch_act(pre, act)
+        if NATIVE_FC_FORWARD and act == ACT_GELU:
+            # one native GEMM writes the activation and the pre-activation from its epilogue
+            h, pre = _ext.C().linear_forward(x2, w_fc, b_fc, act, True)
+        else:
+            pre = F.linear(x2, w_fc, b_fc)
+            h = _torch_act(pre, act)
         y = F.linear(h, w_proj, b_proj)
         ctx.act = act
         ctx.has_b_proj = b_proj is not None

@@ -652,3 +652,29 @@ def test_fused_mlp_matches_reference(act):
     assert not fused_mlp_supported(xs, w1, b1, w2, act)
     y2 = fused_mlp(xs, w1, b1, w2, b2, act)
     torch.testing.assert_close(y2.double(), yr.detach()[:100], rtol=3e-2, atol=3e-2)
+
+
+def test_dgrad_act_backward_gelu_table_over_all_magnitudes():
+    """The epilogue looks GELU' up per bf16 input: every binade from denormal to huge, both signs,
+    zeros and infinities, against the closed form in fp64."""
+    from distributed_pytorch_amd.ops.linear import ACT_GELU
+
+    torch.manual_seed(2)
+    M, N, K = 256, 512, 128
+    dy = torch.randn(M, K, device=DEV).bfloat16()
+    w = (torch.randn(K, N, device=DEV) / 8).bfloat16()
+    mags = torch.cat([torch.tensor([0.0, 1e-40, 1e-30, 1e-10, 2.0 ** -13, 2.0 ** -12, 7.97, 8.0, 30.0, 1e30, float("inf")]),
+                      torch.logspace(-5, 1.2, 4000)])
+    vals = torch.cat([mags, -mags]).to(DEV)
+    aux = vals[torch.randint(0, vals.numel(), (M, N), device=DEV)].bfloat16()
+    aux.view(-1)[: vals.numel()] = vals.bfloat16()  # every probe value at least once
+    assert C().dgrad_act_backward_supported(M, N, K)
+    g, db = C().dgrad_act_backward(dy, w, aux, ACT_GELU, True)
+    x = aux.double()
+    d = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    d = torch.where(torch.isinf(x), (x > 0).double(), d)
+    ref = (dy.double() @ w.double()) * d
+    assert torch.isfinite(g.float()).all()
+    err = (g.double() - ref).abs()
+    assert (err <= 8e-3 * ref.abs() + 2e-3).all(), err.max().item()
+    torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-2, atol=0.15)

@@ -89,15 +89,94 @@ __device__ __forceinline__ void store_from_f32(typename TR::T* p, const float (&
   }
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
+// A few consecutive elements of a row as they sit in memory (16 or 8 bytes per lane), and their
+// expansion to fp32: lets a kernel request data early and keep it packed (half the registers for the
+// 16-bit types) until it is consumed.  V = elements per lane and access.
+typedef __attribute__((ext_vector_type(4))) unsigned int raw16;
+typedef __attribute__((ext_vector_type(2))) unsigned int raw8;
+template <int BYTES>
+struct RawVec;
+template <>
+struct RawVec<16> {
+  using type = raw16;
+  static constexpr int kDwords = 4;
+};
+template <>
+struct RawVec<8> {
+  using type = raw8;
+  static constexpr int kDwords = 2;
+};
+template <typename TR, int V>
+using raw_t = typename RawVec<V * static_cast<int>(sizeof(typename TR::T))>::type;
+
+template <typename TR, int V>
+__device__ __forceinline__ raw_t<TR, V> load_raw(const typename TR::T* p) {
+  return *reinterpret_cast<const raw_t<TR, V>*>(p);
+}
+template <typename TR, int V>
+__device__ __forceinline__ raw_t<TR, V> zero_raw() {
+  raw_t<TR, V> r;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  for (int j = 0; j < RawVec<V * static_cast<int>(sizeof(typename TR::T))>::kDwords; ++j) r[j] = 0u;
+  return r;
+}
+template <typename TR, int V>
+__device__ __forceinline__ void raw_to_f32(const raw_t<TR, V>& r, float (&out)[V]) {
+  if constexpr (sizeof(typename TR::T) == 4) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) out[j] = __uint_as_float(r[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) out[j] = TR::to_f32(static_cast<u16>(j & 1 ? r[j >> 1] >> 16 : r[j >> 1] & 0xffffu));
+  }
+}
+template <typename TR, int V>
+__device__ __forceinline__ void store_raw_from_f32(typename TR::T* p, const float (&in)[V]) {
+  raw_t<TR, V> r;
+  if constexpr (sizeof(typename TR::T) == 4) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) r[j] = __float_as_uint(in[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j)
+      r[j] = static_cast<unsigned>(TR::from_f32(in[2 * j])) | (static_cast<unsigned>(TR::from_f32(in[2 * j + 1])) << 16);
+  }
+  *reinterpret_cast<raw_t<TR, V>*>(p) = r;
+}
+
+// Stops the compiler from expanding a loop-invariant packed vector to fp32 outside the loop (which
+// would double its register footprint for the whole kernel); costs no instruction.
+__device__ __forceinline__ void keep_packed(raw16& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void keep_packed(raw8& r) { asm volatile("" : "+v"(r)); }
+
+// Wave-wide reductions on the data-parallel-primitive path of the VALU (the lane exchange is an operand
+// modifier of the add itself, ~8 cycles per step) instead of six dependent ds_bpermute round trips through
+// the LDS crossbar (~100 cycles each): row-of-16 butterflies, then the row totals are chained across the
+// four rows with row_bcast and lane 63 is read back as a scalar.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140, kDppRowBcast15 = 0x142,
+              kDppRowBcast31 = 0x143;
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_move<kDppQuadXor1, 0xF>(v, 0.f);
+  v += dpp_move<kDppQuadXor2, 0xF>(v, 0.f);
+  v += dpp_move<kDppRowHalfMirror, 0xF>(v, 0.f);
+  v += dpp_move<kDppRowMirror, 0xF>(v, 0.f);
+  v += dpp_move<kDppRowBcast15, 0xA>(v, 0.f);  // rows 1 and 3 += total of the row before
+  v += dpp_move<kDppRowBcast31, 0xC>(v, 0.f);  // rows 2 and 3 += lane 31 (rows 0 + 1)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  constexpr float kLow = -3.402823466e38f;
+  v = fmaxf(v, dpp_move<kDppQuadXor1, 0xF>(v, kLow));
+  v = fmaxf(v, dpp_move<kDppQuadXor2, 0xF>(v, kLow));
+  v = fmaxf(v, dpp_move<kDppRowHalfMirror, 0xF>(v, kLow));
+  v = fmaxf(v, dpp_move<kDppRowMirror, 0xF>(v, kLow));
+  v = fmaxf(v, dpp_move<kDppRowBcast15, 0xA>(v, kLow));
+  v = fmaxf(v, dpp_move<kDppRowBcast31, 0xC>(v, kLow));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Sum across a workgroup of NWAVES waves; every thread gets the result.  `scratch` holds

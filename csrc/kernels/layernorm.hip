@@ -24,8 +24,15 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxBlocks = 2048;
 
-// MAXV = vectors (of TR::kVec elements) per lane; supports cols <= 64 * kVec * MAXV.
-template <typename TR, int MAXV>
+// V = elements per lane and access (16 or 8 bytes), MAXV = accesses per lane and row; a row of
+// `cols` needs cols <= 64 * V * MAXV.  The host picks the 8-byte form when it divides the row evenly
+// over the 64 lanes and the 16-byte form does not (768 columns of bf16: 3 x 4 elements on every lane
+// instead of 2 x 8 on half of them), which saves a quarter of the registers and of the arithmetic.
+// Both kernels are bound by memory-level parallelism, not arithmetic: a wave needs its whole row
+// before the first reduction, so each wave requests the NEXT row it will visit (kept packed in
+// registers) before it starts on the current one, and the per-column parameters are read once per
+// wave instead of once per row.
+template <typename TR, int V, int MAXV>
 __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename TR::T* __restrict__ x,
                                                                  const typename TR::T* __restrict__ res,
                                                                  const typename TR::T* __restrict__ res_bias,
@@ -35,31 +42,68 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
                                                                  typename TR::T* __restrict__ y, float* __restrict__ mean_out,
                                                                  float* __restrict__ rstd_out, long long rows, int cols,
                                                                  float eps) {
-  constexpr int V = TR::kVec;
+  using Raw = raw_t<TR, V>;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nvec = cols / V;
   const float inv_n = 1.f / static_cast<float>(cols);
-  for (long long row = static_cast<long long>(blockIdx.x) * kWaves + wid; row < rows; row += static_cast<long long>(gridDim.x) * kWaves) {
-    const typename TR::T* xr = x + row * cols;
-    float v[MAXV][V];
-    float s = 0.f;
+  const long long stride = static_cast<long long>(gridDim.x) * kWaves;
+  long long row = static_cast<long long>(blockIdx.x) * kWaves + wid;
+
+  Raw gam[MAXV], bet[MAXV], rb[MAXV], nx[MAXV], nr[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    gam[i] = bet[i] = rb[i] = nx[i] = nr[i] = zero_raw<TR, V>();
+    if (vi < nvec) {
+      gam[i] = load_raw<TR, V>(gamma + vi * V);
+      bet[i] = load_raw<TR, V>(beta + vi * V);
+      if (res_bias) rb[i] = load_raw<TR, V>(res_bias + vi * V);
+    }
+  }
+  auto request = [&](long long r) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        load_as_f32<TR, V>(xr + vi * V, v[i]);
+        nx[i] = load_raw<TR, V>(x + r * cols + vi * V);
+        if (res) nr[i] = load_raw<TR, V>(res + r * cols + vi * V);
+      }
+    }
+  };
+  if (row < rows) request(row);
+  for (; row < rows; row += stride) {
+    Raw cx[MAXV], cr[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      cx[i] = nx[i];
+      cr[i] = nr[i];
+    }
+    if (row + stride < rows) request(row + stride);
+    float v[MAXV][V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      keep_packed(gam[i]);
+      keep_packed(bet[i]);
+      keep_packed(rb[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        raw_to_f32<TR, V>(cx[i], v[i]);
         if (res) {
           float r[V];
-          load_as_f32<TR, V>(res + row * cols + vi * V, r);
+          raw_to_f32<TR, V>(cr[i], r);
           if (res_bias) {  // the bias of the layer that produced `res`, added here instead of in its GEMM
-            float rb[V];
-            load_as_f32<TR, V>(res_bias + vi * V, rb);
+            float b[V];
+            raw_to_f32<TR, V>(rb[i], b);
 #pragma unroll
-            for (int j = 0; j < V; ++j) r[j] = TR::to_f32(TR::from_f32(r[j] + rb[j]));
+            for (int j = 0; j < V; ++j) r[j] = TR::to_f32(TR::from_f32(r[j] + b[j]));
           }
 #pragma unroll
           for (int j = 0; j < V; ++j) v[i][j] = TR::to_f32(TR::from_f32(v[i][j] + r[j]));
-          store_from_f32<TR, V>(sum_out + row * cols + vi * V, v[i]);
+          store_raw_from_f32<TR, V>(sum_out + row * cols + vi * V, v[i]);
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) s += v[i][j];
@@ -88,11 +132,11 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
       const int vi = lane + 64 * i;
       if (vi < nvec) {
         float g[V], b[V], o[V];
-        load_as_f32<TR, V>(gamma + vi * V, g);
-        load_as_f32<TR, V>(beta + vi * V, b);
+        raw_to_f32<TR, V>(gam[i], g);
+        raw_to_f32<TR, V>(bet[i], b);
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-        store_from_f32<TR, V>(yr + vi * V, o);
+        store_raw_from_f32<TR, V>(yr + vi * V, o);
       }
     }
   }
@@ -100,51 +144,84 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
 
 // DSUM: also accumulate the column sums of dx (the gradient of a bias that was added to the
 // residual operand in the forward); the partial rows then hold 3*cols values instead of 2*cols.
-template <typename TR, int MAXV, bool DSUM>
-__global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename TR::T* __restrict__ dy,
-                                                                 const typename TR::T* __restrict__ x,
-                                                                 const typename TR::T* __restrict__ dres,
-                                                                 const typename TR::T* __restrict__ gamma,
-                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                                 typename TR::T* __restrict__ dx, float* __restrict__ partial,
-                                                                 long long rows, int cols) {
-  constexpr int V = TR::kVec;
-  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [kWaves][NACC][cols]
+template <typename TR, int V, int MAXV, bool DSUM>
+__global__ __launch_bounds__(kThreads, V* MAXV <= 12 ? 4 : (V * MAXV <= 16 ? 3 : 1)) void layernorm_bwd_kernel(
+    const typename TR::T* __restrict__ dy, const typename TR::T* __restrict__ x, const typename TR::T* __restrict__ dres,
+    const typename TR::T* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    typename TR::T* __restrict__ dx, float* __restrict__ partial, long long rows, int cols) {
+  using Raw = raw_t<TR, V>;
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [NACC][cols]
   constexpr int NACC = DSUM ? 3 : 2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nvec = cols / V;
   const float inv_n = 1.f / static_cast<float>(cols);
+  const long long stride = static_cast<long long>(gridDim.x) * kWaves;
+  long long row = static_cast<long long>(blockIdx.x) * kWaves + wid;
 
-  float gam[MAXV][V], dg[MAXV][V], db[MAXV][V], ds[DSUM ? MAXV : 1][V];
+  Raw gam[MAXV], nx[MAXV], ng[MAXV];
+  float dg[MAXV][V], db[MAXV][V], ds[DSUM ? MAXV : 1][V];
+  float nmean = 0.f, nrstd = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int vi = lane + 64 * i;
-    if (vi < nvec) load_as_f32<TR, V>(gamma + vi * V, gam[i]);
+    gam[i] = nx[i] = ng[i] = zero_raw<TR, V>();
+    if (vi < nvec) gam[i] = load_raw<TR, V>(gamma + vi * V);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       dg[i][j] = db[i][j] = 0.f;
       if (DSUM) ds[i][j] = 0.f;
     }
   }
-
-  for (long long row = static_cast<long long>(blockIdx.x) * kWaves + wid; row < rows; row += static_cast<long long>(gridDim.x) * kWaves) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float xh[MAXV][V], gy[MAXV][V];
-    float s1 = 0.f, s2 = 0.f;
+  auto request = [&](long long r) __attribute__((always_inline)) {
+    nmean = mean_in[r];
+    nrstd = rstd_in[r];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        load_as_f32<TR, V>(x + row * cols + vi * V, xh[i]);
-        load_as_f32<TR, V>(dy + row * cols + vi * V, gy[i]);
+        nx[i] = load_raw<TR, V>(x + r * cols + vi * V);
+        ng[i] = load_raw<TR, V>(dy + r * cols + vi * V);
+      }
+    }
+  };
+  if (row < rows) request(row);
+  for (; row < rows; row += stride) {
+    const float mean = nmean, rstd = nrstd;
+    Raw cx[MAXV], cg[MAXV], cr[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      cx[i] = nx[i];
+      cg[i] = ng[i];
+      cr[i] = zero_raw<TR, V>();
+    }
+    if (row + stride < rows) request(row + stride);
+    // the residual-path gradient is only needed after the reductions: requested now, for this row
+    if (dres) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nvec) cr[i] = load_raw<TR, V>(dres + row * cols + (lane + 64 * i) * V);
+    }
+    // The row stays packed across the two reductions and is expanded a second time afterwards:
+    // 3 VALU operations per element are cheaper than the registers fp32 copies would hold.
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) keep_packed(gam[i]);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + 64 * i;
+      if (vi < nvec) {
+        float g[V], xh[V], gy[V];
+        raw_to_f32<TR, V>(cx[i], xh);
+        raw_to_f32<TR, V>(cg[i], gy);
+        raw_to_f32<TR, V>(gam[i], g);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          xh[i][j] = (xh[i][j] - mean) * rstd;
-          dg[i][j] += gy[i][j] * xh[i][j];
-          db[i][j] += gy[i][j];
-          gy[i][j] *= gam[i][j];
-          s1 += gy[i][j];
-          s2 += gy[i][j] * xh[i][j];
+          xh[j] = (xh[j] - mean) * rstd;
+          dg[i][j] += gy[j] * xh[j];
+          db[i][j] += gy[j];
+          gy[j] *= g[j];
+          s1 += gy[j];
+          s2 += gy[j] * xh[j];
         }
       }
     }
@@ -152,14 +229,22 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
     s2 = wave_sum(s2) * inv_n;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
+      keep_packed(cx[i]);
+      keep_packed(cg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        float o[V];
+        float g[V], xh[V], gy[V], o[V];
+        raw_to_f32<TR, V>(cx[i], xh);
+        raw_to_f32<TR, V>(cg[i], gy);
+        raw_to_f32<TR, V>(gam[i], g);
 #pragma unroll
-        for (int j = 0; j < V; ++j) o[j] = rstd * (gy[i][j] - s1 - xh[i][j] * s2);
+        for (int j = 0; j < V; ++j) o[j] = rstd * (gy[j] * g[j] - s1 - (xh[j] - mean) * rstd * s2);
         if (dres) {
           float r[V];
-          load_as_f32<TR, V>(dres + row * cols + vi * V, r);
+          raw_to_f32<TR, V>(cr[i], r);
 #pragma unroll
           for (int j = 0; j < V; ++j) o[j] += r[j];
         }
@@ -167,34 +252,39 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const typename 
 #pragma unroll
           for (int j = 0; j < V; ++j) ds[i][j] += o[j];
         }
-        store_from_f32<TR, V>(dx + row * cols + vi * V, o);
+        store_raw_from_f32<TR, V>(dx + row * cols + vi * V, o);
       }
     }
   }
 
-  // Combine the workgroup's waves through LDS, then one partial row per workgroup.
-  float* sg = ln_smem + static_cast<size_t>(wid) * NACC * cols;
-  float* sb = sg + cols;
+  // Combine the workgroup's waves through one LDS row set, wave after wave (a lane owns the same
+  // columns in every wave, so the turns need no atomics), then one partial row per workgroup.
+  for (int w = 0; w < kWaves; ++w) {
+    if (wid == w) {
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int vi = lane + 64 * i;
-    if (vi < nvec) {
+      for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        sg[vi * V + j] = dg[i][j];
-        sb[vi * V + j] = db[i][j];
-        if (DSUM) sb[cols + vi * V + j] = ds[i][j];
+          for (int j = 0; j < V; ++j) {
+            const int c = vi * V + j;
+            if (w == 0) {
+              ln_smem[c] = dg[i][j];
+              ln_smem[cols + c] = db[i][j];
+              if (DSUM) ln_smem[2 * cols + c] = ds[i][j];
+            } else {
+              ln_smem[c] += dg[i][j];
+              ln_smem[cols + c] += db[i][j];
+              if (DSUM) ln_smem[2 * cols + c] += ds[i][j];
+            }
+          }
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* out = partial + static_cast<size_t>(blockIdx.x) * NACC * cols;
-  for (int c = threadIdx.x; c < NACC * cols; c += kThreads) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) s += ln_smem[static_cast<size_t>(w) * NACC * cols + c];
-    out[c] = s;
-  }
+  for (int c = threadIdx.x; c < NACC * cols; c += kThreads) out[c] = ln_smem[c];
 }
 
 // dgamma / dbeta = column sums of the per-workgroup partial rows.  16 outputs per workgroup, 16 row
@@ -238,13 +328,24 @@ int pick_blocks(long long rows) {
   return static_cast<int>(b);
 }
 
-template <typename F>
-bool dispatch_maxv(int need, int limit, F&& f) {
-  if (need > limit) return false;
-  if (need <= 1) f(std::integral_constant<int, 1>{});
-  else if (need <= 2) f(std::integral_constant<int, 2>{});
-  else if (need <= 4) f(std::integral_constant<int, 4>{});
-  else f(std::integral_constant<int, 8>{});
+// Calls f(V, MAXV) as integral constants for a row of `cols` elements: the 8-byte access form when it
+// spreads the row evenly over the wave and the 16-byte form does not, the 16-byte form otherwise.
+template <typename TR, typename F>
+bool dispatch_shape(long long cols, int limit16, F&& f) {
+  constexpr int V16 = TR::kVec, V8 = TR::kVec / 2;
+  const long long n16 = cols / V16, n8 = cols / V8;
+  if (n16 % 64 != 0 && cols % V8 == 0 && n8 % 64 == 0) {
+    const long long m = n8 / 64;
+    if (m == 1) { f(std::integral_constant<int, V8>{}, std::integral_constant<int, 1>{}); return true; }
+    if (m == 3) { f(std::integral_constant<int, V8>{}, std::integral_constant<int, 3>{}); return true; }
+    if (m == 5) { f(std::integral_constant<int, V8>{}, std::integral_constant<int, 5>{}); return true; }
+  }
+  const int need = static_cast<int>((n16 + 63) / 64);
+  if (need > limit16) return false;
+  if (need <= 1) f(std::integral_constant<int, V16>{}, std::integral_constant<int, 1>{});
+  else if (need <= 2) f(std::integral_constant<int, V16>{}, std::integral_constant<int, 2>{});
+  else if (need <= 4) f(std::integral_constant<int, V16>{}, std::integral_constant<int, 4>{});
+  else f(std::integral_constant<int, V16>{}, std::integral_constant<int, 8>{});
   return true;
 }
 
@@ -256,12 +357,11 @@ void launch_layernorm_fwd(const void* x, const void* res, const void* res_bias, 
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
     using T = typename TR::T;
-    const int need = static_cast<int>((cols / TR::kVec + 63) / 64);
     long long blocks = (rows + kWaves - 1) / kWaves;
     if (blocks > 4096) blocks = 4096;
-    dispatch_maxv(need, 8, [&](auto mv) {
-      constexpr int MAXV = decltype(mv)::value;
-      hipLaunchKernelGGL((layernorm_fwd_kernel<TR, MAXV>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream,
+    dispatch_shape<TR>(cols, 8, [&](auto vv, auto mv) {
+      constexpr int V = decltype(vv)::value, MAXV = decltype(mv)::value;
+      hipLaunchKernelGGL((layernorm_fwd_kernel<TR, V, MAXV>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream,
                          static_cast<const T*>(x), static_cast<const T*>(res), static_cast<const T*>(res_bias), static_cast<T*>(sum_out),
                          static_cast<const T*>(gamma),
                          static_cast<const T*>(beta), static_cast<T*>(y), mean, rstd, rows, static_cast<int>(cols), eps);
@@ -278,15 +378,15 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
     using T = typename TR::T;
-    const int need = static_cast<int>((cols / TR::kVec + 63) / 64);
     const int blocks = pick_blocks(rows);
     const int nacc = dsum ? 3 : 2;
-    const size_t lds = static_cast<size_t>(kWaves) * nacc * cols * sizeof(float);
-    dispatch_maxv(need, 4, [&](auto mv) {
-      constexpr int MAXV = decltype(mv)::value > 4 ? 4 : decltype(mv)::value;
+    const size_t lds = static_cast<size_t>(nacc) * cols * sizeof(float);
+    dispatch_shape<TR>(cols, 4, [&](auto vv, auto mv) {
+      constexpr int V = decltype(vv)::value;
+      constexpr int MAXV = decltype(mv)::value > 5 ? 4 : decltype(mv)::value;
       auto go = [&](auto ds_tag) {
         constexpr bool DS = decltype(ds_tag)::value;
-        hipLaunchKernelGGL((layernorm_bwd_kernel<TR, MAXV, DS>), dim3(blocks), dim3(kThreads), lds, stream, static_cast<const T*>(dy),
+        hipLaunchKernelGGL((layernorm_bwd_kernel<TR, V, MAXV, DS>), dim3(blocks), dim3(kThreads), lds, stream, static_cast<const T*>(dy),
                            static_cast<const T*>(x), static_cast<const T*>(dres), static_cast<const T*>(gamma), mean, rstd, static_cast<T*>(dx),
                            workspace, rows, static_cast<int>(cols));
       };

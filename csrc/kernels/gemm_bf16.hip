@@ -625,7 +625,25 @@ int gemm_bf16_split_k(const GemmArgs& a) {
   if (a.K % BK2 != 0 || a.N % 4 != 0 || a.M < 8 || a.N < 8) return 1;
   const long long tiles = ((a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
   const long long nk = a.K / BK2;
-  if (tiles >= 128 || nk < 32) return 1;
+  if (nk < 32) return 1;
+  if (tiles >= 128) {
+    // Enough tiles to fill the chip, but a tile count just above a multiple of the 256 CUs leaves the
+    // last round mostly idle (591 tiles of a [50304, 768] weight gradient: 3 rounds for 2.3 rounds of
+    // work).  With a long contraction, s ranges per tile make the rounds s times shorter and the tail
+    // with them; taken when that saves at least a tenth and the fp32 partials stay below 1 GiB.
+    if (nk < 256) return 1;
+    int best = 1;
+    double best_cost = static_cast<double>((tiles + 255) / 256);
+    const double base = best_cost;
+    for (int s = 2; s <= 4; ++s) {
+      const double cost = static_cast<double>((tiles * s + 255) / 256) / s;
+      if (cost < best_cost - 1e-9 && static_cast<double>(s) * a.M * a.N * 4.0 <= 1073741824.0) {
+        best_cost = cost;
+        best = s;
+      }
+    }
+    return best_cost <= 0.9 * base ? best : 1;
+  }
   // One workgroup per CU (128 KiB of LDS each): aim for one full wave of 256 workgroups, with at
   // least 16 contraction steps per range so the pipeline prologue stays amortised.
   long long s = 256 / tiles;

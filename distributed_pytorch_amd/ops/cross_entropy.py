@@ -79,7 +79,14 @@ class _ProjectionXent(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dlogits, weight).mul_(g)
         if ctx.needs_input_grad[1]:
-            dw = torch.mm(dlogits.t(), x2).mul_(g)
+            # [vocabulary, K] with the whole token count as contraction: the native kernel where it splits the
+            # contraction to fill the last round of tiles, the vendor GEMM otherwise
+            C = _ext.C()
+            if (dlogits.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+                    and C.gemm_bf16_split_k(dlogits.shape[1], x2.shape[1], dlogits.shape[0], False, False) > 1):
+                dw = C.gemm(dlogits, x2, False, False).mul_(g)
+            else:
+                dw = torch.mm(dlogits.t(), x2).mul_(g)
         return dx, dw, None, None, None, None
 
 

@@ -41,6 +41,8 @@ def parse_args(argv=None):
     p.add_argument("--seq-len", type=int, default=1024)
     p.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="compute dtype (default bf16; dummy: fp32)")
     p.add_argument("--linear-impl", default=os.environ.get("BENCH_LINEAR_IMPL", "library"), choices=["auto", "native", "library", "stock"])
+    p.add_argument("--widemlp-gemm", default="native", choices=["native", "library"],
+                   help="Wide MLP: forward / input-gradient GEMMs on the hand-written kernel (default) or the vendor library")
     p.add_argument("--attention-impl", default="auto", choices=["auto", "native", "sdpa"], help="GPT-2 attention kernel (ablation)")
     p.add_argument("--no-fused-mlp", action="store_true", help="GPT-2: separate c_fc / GELU / c_proj autograd nodes (ablation)")
     p.add_argument("--no-fused-qkv-attention", action="store_true", help="GPT-2: c_attn and attention as separate autograd nodes (ablation)")
@@ -88,7 +90,7 @@ def build_workload(args, device):
     if name == "widemlp":
         dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
         B = args.batch_size or 8192
-        model = WideMLP(8192, 8192, 8, 1024).to(device=device, dtype=dtype)
+        model = WideMLP(8192, 8192, 8, 1024, linear_impl=args.widemlp_gemm).to(device=device, dtype=dtype)
         x = torch.randn(B, 8192, generator=g).to(device=device, dtype=dtype)
         y = torch.randint(0, 1024, (B,), generator=g).to(device)
         crit = SoftmaxCrossEntropy()

@@ -15,11 +15,12 @@ from ..ops.linear import Linear
 
 
 class WideMLP(nn.Module):
-    def __init__(self, in_dim: int = 8192, hidden: int = 8192, depth: int = 8, n_classes: int = 1024, act: str = "relu"):
+    def __init__(self, in_dim: int = 8192, hidden: int = 8192, depth: int = 8, n_classes: int = 1024, act: str = "relu",
+                 linear_impl: str = "native"):
         super().__init__()
         dims = [in_dim] + [hidden] * depth
-        self.layers = nn.ModuleList([Linear(dims[i], dims[i + 1], act=act) for i in range(depth)])
-        self.head = Linear(hidden, n_classes)
+        self.layers = nn.ModuleList([Linear(dims[i], dims[i + 1], act=act, impl=linear_impl) for i in range(depth)])
+        self.head = Linear(hidden, n_classes, impl=linear_impl)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         for layer in self.layers:

@@ -164,14 +164,22 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 class Linear(nn.Linear):
     """``nn.Linear`` (same parameters, same ``state_dict`` keys) with an optional fused
-    activation, computed by the native kernels on the GPU."""
+    activation.  ``impl="native"`` computes everything on the hand-written kernels;
+    ``impl="library"`` sends the forward and input-gradient GEMMs to the vendor library and keeps the
+    activation backward, bias gradient and split-K weight gradient on ours."""
 
-    def __init__(self, in_features: int, out_features: int, bias: bool = True, act=None, device=None, dtype=None):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, act=None, device=None, dtype=None,
+                 impl: str = "native"):
         super().__init__(in_features, out_features, bias=bias, device=device, dtype=dtype)
+        if impl not in ("native", "library"):
+            raise ValueError(f"impl must be native | library, got {impl}")
         self.act = act
+        self.impl = impl
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.impl == "library" and x.is_cuda:
+            return library_linear_bias_act(x, self.weight, self.bias, self.act)
         return linear_bias_act(x, self.weight, self.bias, self.act)
 
     def extra_repr(self) -> str:
-        return super().extra_repr() + (f", act={self.act}" if self.act else "")
+        return super().extra_repr() + (f", act={self.act}" if self.act else "") + (f", impl={self.impl}" if self.impl != "native" else "")

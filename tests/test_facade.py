@@ -205,3 +205,32 @@ def test_gemm_tuning_is_inert_without_a_gpu_and_profile_summaries_parse(tmp_path
     out = profile.pmc_summary(str(p), "dpa::")
     assert len(out) == 1 and out[0]["dispatches"] == 2 and out[0]["avg_us"] == 0.5
     assert out[0]["mfma_busy_pct"] == 50.0  # 512000 / (1000 cycles * 1024 SIMDs)
+
+
+def test_split_k_heuristic_fills_the_last_round_of_tiles():
+    """Host-side planning of the bf16 GEMM: few tiles with a long contraction split to fill the chip,
+    many tiles split only when the tile count sits just above a multiple of the 256 CUs."""
+    from distributed_pytorch_amd import _ext
+
+    if not _ext.have_C():
+        pytest.skip("extension not built")
+    split = _ext.C().gemm_bf16_split_k
+    assert split(768, 3072, 65536, False, False) > 1          # 36 tiles, 1024 k-steps
+    assert split(50304, 768, 262144, False, False) == 3       # 591 tiles: 3 rounds -> 7 thirds
+    assert split(8192, 8192, 8192, False, False) == 1         # 1024 tiles = 4 full rounds
+    assert split(50304, 768, 4096, False, False) == 1         # contraction too short to amortise the reduce
+    assert split(65536, 3072, 768, True, True) == 1           # forward shape: many tiles, short K
+
+
+def test_linear_module_impl_switch_keeps_parameters_and_cpu_path():
+    import torch
+    from distributed_pytorch_amd.ops.linear import Linear
+
+    torch.manual_seed(0)
+    a, b = Linear(16, 8, act="relu"), Linear(16, 8, act="relu", impl="library")
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(4, 16)
+    assert torch.equal(a(x), b(x))
+    assert list(a.state_dict()) == ["weight", "bias"] and "impl=library" in repr(b)
+    with pytest.raises(ValueError):
+        Linear(4, 4, impl="other")

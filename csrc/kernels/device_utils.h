@@ -221,6 +221,18 @@ __device__ __forceinline__ float gelu_grad(float x) {
   return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// Phi(x), the standard normal distribution function, in the same rational erfc form.
+__device__ __forceinline__ float normal_cdf(float x) {
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float tail = 0.5f * poly * t * e;
+  return x >= 0.f ? 1.f - tail : tail;
+}
+
 // GELU(x) = x * Phi(x) with the same rational erfc form as gelu_grad: branch-free, one v_exp and one
 // v_rcp (libm's erff costs several divergent branches per element, which an MFMA GEMM epilogue that
 // runs 128 elements per lane cannot hide).

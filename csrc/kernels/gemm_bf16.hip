@@ -232,7 +232,7 @@ __device__ __forceinline__ int kmajor2_off(int row, int c) { return row * 128 + 
 __device__ __forceinline__ int rmajor2_off(int k, int c) { return k * 512 + ((c ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)))) << 4); }
 
 // GELU'(x) of a bf16 x only takes 65536 values, and outside 2^-12 <= |x| < 8 it is 0.5, 0 or 1 to well
-// below bf16 resolution: the activation-backward epilogue looks the derivative up in an LDS table
+// below bf16 resolution (likewise Phi(x) for the forward, GELU(x) = x * Phi(x)): the epilogues look it up in an LDS table
 // (15 binades x 128 mantissas per sign, fp32 entries computed by the workgroup itself while its first
 // tile is in flight) instead of evaluating exp / rcp / eight FMAs per element -- with one workgroup per
 // CU nothing overlaps the epilogue's VALU work, which used to take as long as nine k-steps.
@@ -323,11 +323,14 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
   extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 stages][A tile | B tile][GELU' table]
 
   float* gelu_tab = reinterpret_cast<float*>(smem2 + 4 * kTileBytes2);
-  if (!SPLIT && p.aux_mode == kActGelu) {
+  if (!SPLIT && (p.aux_mode == kActGelu || p.act == kActGelu)) {
+    // backward epilogue: GELU'(x); forward epilogue: Phi(x), so that GELU(x) = x * table[x]
+    const bool derivative = p.aux_mode == kActGelu;
     for (int e = threadIdx.x; e < 2 * kGeluEntries; e += kThreads2) {
       const bool neg = e >= kGeluEntries;
       const unsigned bits = static_cast<unsigned>(kGeluLo + (neg ? e - kGeluEntries : e)) | (neg ? 0x8000u : 0u);
-      gelu_tab[e] = gelu_grad(__uint_as_float(bits << 16));
+      const float x = __uint_as_float(bits << 16);
+      gelu_tab[e] = derivative ? gelu_grad(x) : normal_cdf(x);
     }
     __syncthreads();
   }
@@ -492,7 +495,14 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
           for (int e = 0; e < 4; ++e) {
             o[e] = BF16::from_f32(p.alpha * a[e] + bv[j][e]);
             // the activation sees the pre-activation rounded to bf16, exactly as the unfused path stores and re-reads it
-            if (ACT != kActNone) o[e] = BF16::from_f32(act_fn(BF16::to_f32(o[e]), ACT));
+            if (ACT == kActGelu) {
+              const int bits = o[e];
+              int idx = (bits & 0x7fff) - kGeluLo;
+              idx = idx < 0 ? 0 : (idx > kGeluEntries - 1 ? kGeluEntries - 1 : idx);
+              o[e] = BF16::from_f32(BF16::to_f32(o[e]) * gelu_tab[idx + (bits >> 15) * kGeluEntries]);
+            } else if (ACT != kActNone) {
+              o[e] = BF16::from_f32(act_fn(BF16::to_f32(o[e]), ACT));
+            }
           }
           *reinterpret_cast<u16x4*>(mine + (16 * ii + (lane & 15)) * kPitch + (16 * j + 4 * (lane >> 4)) * 2) = o;
         }

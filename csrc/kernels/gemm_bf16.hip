@@ -370,7 +370,15 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
   // scheduler would otherwise sink each read next to its first use and expose the LDS latency in
   // front of every group of four MFMAs).  A phase-shifted schedule (wave groups alternating between
   // reading and multiplying) and per-half fragment double buffering were measured on 8192^3 and on
-  // the GPT-2 shapes and came out 3-10 % slower than this arrangement.
+  // the GPT-2 shapes and came out 3-10 % slower than this arrangement.  Timing variants of this loop
+  // on 8192^3 (harness, uniform random operands, 1.14 PFLOP/s as is): every request re-reading one
+  // L2-resident k-tile 1.21, no requests at all 1.38, no barrier 1.21, neither 1.45 -- the LDS-DMA
+  // traffic itself (64 KiB of LDS writes per k-step next to 192 KiB of fragment reads) costs more than
+  // memory latency or the barrier.  Moving the barrier and the next step's first fragment reads into
+  // the middle of the MFMA stream (so that no MFMA ever waits on LDS latency) changed nothing, and a
+  // 4-wave variant with 128 x 128 per wave (512 registers, a third less LDS read traffic) fell to
+  // 0.88: with one wave per SIMD nothing covers the read bursts unless reads and MFMAs are interleaved
+  // instruction by instruction, which the compiler does not do.
   bf16x8 fa[2][8], fb[2][4];
   auto read_frags = [&](int stage) {
     const char* as = smem2 + stage * 2 * kTileBytes2;

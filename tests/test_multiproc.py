@@ -183,3 +183,28 @@ def test_sigterm_on_launcher_kills_workers(tmp_path):
                 break
             assert time.time() < deadline, f"worker {pid} outlived the launcher"
             time.sleep(0.1)
+
+
+def test_bench_under_torch_distributed_run_two_ranks():
+    """The launch line of the scaling benchmark: torch.distributed.run owns MASTER_PORT with its own
+    store, the ranks rendezvous through it, rank 0 prints exactly one JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "dummy",
+           "--batch-size", "256", "--backend", "gloo"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["steps"] == 2 and rec["warmup"] == 1 and rec["config"]["parallelism"] == "dp2"
+    assert rec["config"]["global_batch"] == 512 and rec["config"]["comm"] == "gloo" and rec["value"] > 0

@@ -230,3 +230,22 @@ def test_bench_two_ranks_on_one_gpu_gloo_ddp_contract():
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 1024 and r["config"]["parallelism"] == "dp2"
     assert r["steps"] == 2 and r["warmup"] == 1 and r["value"] > 0
+
+
+def test_rccl_group_through_torch_distributed_run_store():
+    """The rendezvous path of the multi-GPU benchmark (torch.distributed.run hosts the store on
+    MASTER_PORT, the ncclUniqueId travels through it), at the world size one GPU allows."""
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "rccl_torchrun_probe.py")]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "rccl over the launcher store ok: world 1" in out.stdout

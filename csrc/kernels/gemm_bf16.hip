@@ -464,7 +464,11 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
   // contiguous bytes per store instruction.  Bias and activation are applied in registers first.
   // (A persistent one-workgroup-per-CU variant that requests the next tile's first k-step before the
   // epilogue was measured 10-20 % slower: its top-of-loop vmcnt(0) also waits for the output stores
-  // to drain, which the hardware overlaps for free when a fresh workgroup takes over the CU.  A
+  // to drain, which the hardware overlaps for free when a fresh workgroup takes over the CU; a second
+  // attempt that requested the next tile after the last k-step, kept the epilogue inside the last stage
+  // and waited for the request before the first store was 4-7 % faster than one workgroup per tile in
+  // the same code, but the tile loop around the main loop cost registers the main loop does not have
+  // (64-106 spilled VGPRs, some inside the k-loop of the NN / TN variants) and the sum was 20 % slower.  A
   // 128x256x32 tile with two independent 4-wave workgroups per CU, meant to cover one workgroup's
   // prologue / epilogue with the other's main loop, was 7-20 % slower as well: half the MFMAs per
   // barrier and 1.5x the global->LDS traffic per flop cost more than the overlap returns.)

@@ -313,7 +313,7 @@ def test_gemm_large_random_f32_and_bf16():
 
 
 # ----------------------------------------------------------------------------- layer norm
-@pytest.mark.parametrize("rows,cols", [(1, 768), (5, 768), (4097, 768), (33, 64), (16, 1024), (7, 2048)])
+@pytest.mark.parametrize("rows,cols", [(1, 768), (5, 768), (4097, 768), (33, 64), (16, 1024), (7, 2048), (9, 1280), (12, 256), (6, 384), (10, 320)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm(rows, cols, dtype):
     from distributed_pytorch_amd.ops.layernorm import layer_norm

@@ -208,3 +208,23 @@ def test_bench_under_torch_distributed_run_two_ranks():
     rec = json.loads(lines[0])
     assert rec["steps"] == 2 and rec["warmup"] == 1 and rec["config"]["parallelism"] == "dp2"
     assert rec["config"]["global_batch"] == 512 and rec["config"]["comm"] == "gloo" and rec["value"] > 0
+
+
+def test_example_training_script_two_ranks_checkpoint_and_resume(tmp_path):
+    """examples/train_gpt2.py end to end on two gloo ranks: sampler, prefetcher, DDP, fused optimizer,
+    logging, checkpoint; a second invocation resumes from the saved step."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ckpt = str(tmp_path / "gpt2.pt")
+    base = [sys.executable, os.path.join(root, "examples", "train_gpt2.py"), "--n-layer", "2", "--n-embd", "64", "--n-head", "2",
+            "--seq-len", "32", "--vocab-size", "512", "--batch-size", "8", "--data-size", "256", "--log-every", "4", "--ckpt", ckpt]
+    env = dict(os.environ, DIST_WORLD_SIZE="2", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    first = subprocess.run(base + ["--steps", "8"], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert first.returncode == 0, first.stderr[-2000:]
+    recs = [json.loads(ln) for ln in first.stdout.splitlines() if ln.startswith("{")]
+    assert [r["step"] for r in recs] == [4, 8] and all(r["loss"] > 0 for r in recs)
+    assert "saved" in first.stdout and os.path.exists(ckpt)
+    second = subprocess.run(base + ["--steps", "12", "--resume"], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert second.returncode == 0, second.stderr[-2000:]
+    assert "resumed from" in second.stdout and "at step 8" in second.stdout
+    recs2 = [json.loads(ln) for ln in second.stdout.splitlines() if ln.startswith("{")]
+    assert [r["step"] for r in recs2] == [12]

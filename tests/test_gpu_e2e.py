@@ -96,6 +96,41 @@ def test_ddp_wrapper_over_rccl_matches_plain_module(rccl_group):
         torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-6)
 
 
+def test_gpt2_with_fused_nodes_under_the_reducer_matches_plain_training(rccl_group):
+    """GPT-2 (tied embedding / lm-head weight, fused MLP, projection + attention and lm-head + loss nodes)
+    wrapped in the data-parallel module: bucket hooks fire for every parameter, gradients live in the
+    arena, and five steps give exactly the weights of unwrapped training."""
+    from distributed_pytorch_amd.models import GPT2, GPT2Config
+    from distributed_pytorch_amd.ops import FusedAdamW
+    from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+    cfg = GPT2Config(block_size=256, vocab_size=1000, n_layer=2, n_head=2, n_embd=128, linear_impl="library")
+    torch.manual_seed(0)
+    plain = GPT2(cfg).to(DEV).bfloat16()
+    twin = GPT2(cfg).to(DEV).bfloat16()
+    twin.load_state_dict(plain.state_dict())
+    ddp = DistributedDataParallel(twin, device_ids=[0], bucket_cap_mb=0.25, first_bucket_mb=0.05)
+    assert ddp.reducer.num_buckets() >= 3
+    o1 = FusedAdamW(plain.parameters(), 1e-3, master_weights=True)
+    o2 = FusedAdamW(ddp.parameters(), 1e-3, master_weights=True)
+    g = torch.Generator().manual_seed(1)
+    losses = ([], [])
+    for step in range(5):
+        idx = torch.randint(0, 1000, (4, 256), generator=g).to(DEV)
+        tgt = torch.randint(0, 1000, (4, 256), generator=g).to(DEV)
+        for k, (model, opt) in enumerate(((plain, o1), (ddp, o2))):
+            opt.zero_grad(set_to_none=True)
+            loss = model(idx, tgt)
+            loss.backward()
+            opt.step()
+            losses[k].append(loss.item())
+    assert ddp.reducer.num_backward_syncs() == 5
+    assert ddp.reducer.num_bucket_launches() == 5 * ddp.reducer.num_buckets()
+    assert losses[0] == losses[1], losses
+    for (n, a), b in zip(plain.named_parameters(), ddp.module.parameters()):
+        assert torch.equal(a, b), n
+
+
 def test_ddp_bf16_params_fp32_reduce(rccl_group):
     from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
 

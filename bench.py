@@ -71,9 +71,10 @@ def build_workload(args, device):
     g = torch.Generator(device="cpu").manual_seed(1234 + int(os.environ.get("RANK", "0")))
     if name in ("gpt2", "gpt2-medium"):
         dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
-        # per-GPU batch sized for 288 GB of HBM: 256 sequences of GPT-2 small peak at 100 GB and run 5 % more
-        # samples/s than 64 (longer contractions in the weight-gradient GEMMs, fewer launches per sample)
-        B = args.batch_size or (256 if (name == "gpt2" and device.type == "cuda") else 64)
+        # per-GPU batch sized for 288 GB of HBM: 384 sequences of GPT-2 small peak at 149 GB allocated / 185 GB
+        # reserved and run 4.5 % more samples/s than 64 (longer contractions in the weight-gradient GEMMs,
+        # fewer launches per sample; 256: -0.6 %, 512: +0.6 % but 246 GB reserved)
+        B = args.batch_size or (384 if (name == "gpt2" and device.type == "cuda") else 64)
         T = args.seq_len
         cfg = (GPT2Config.small if name == "gpt2" else GPT2Config.medium)(
             block_size=max(T, 1024), linear_impl="stock" if args.stock else args.linear_impl, native_ops=not args.stock,
@@ -248,6 +249,7 @@ def run_rank(rank: int, world_size: int, argv):
     }
     if use_gpu:
         result["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
+        result["peak_reserved_gb"] = round(torch.cuda.max_memory_reserved(device) / 2**30, 2)
     if dist.is_primary():
         line = json.dumps(result)
         print(line, flush=True)

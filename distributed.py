@@ -19,7 +19,6 @@ multi-process CPU run (``DIST_WORLD_SIZE`` / ``nprocs=``); ``prepare_ddp_model``
 from __future__ import annotations
 
 import socket
-from contextlib import closing
 
 import torch
 from torch.distributed import ReduceOp  # enum kept so reduce(op=ReduceOp.SUM) call sites work
@@ -43,10 +42,13 @@ def find_free_port():
     ``launch`` does not depend on it -- the launcher binds its store to port 0 itself --
     but it stays available for scripts that export ``MASTER_PORT`` by hand.
     """
-    with closing(socket.socket(socket.AF_INET, socket.SOCK_STREAM)) as s:
-        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        s.bind(("", 0))
-        return s.getsockname()[1]
+    probe = socket.socket()
+    try:
+        probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)  # before bind, where it has an effect
+        probe.bind(("127.0.0.1", 0))  # port 0: the kernel picks an unused one
+        return probe.getsockname()[1]
+    finally:
+        probe.close()
 
 
 def launch(worker_fn, *args, nprocs=None):
@@ -86,14 +88,14 @@ def get_world_size():
     return _pg.get_world_size()
 
 
-# data loading stuff
+# ---- input sharding
 def data_sampler(dataset, distributed, shuffle):
     if distributed:
         return ShardedSampler(dataset, shuffle=shuffle)
     return None
 
 
-# model wrapping
+# ---- data-parallel wrapper
 def prepare_ddp_model(model, device_ids, *args, **kwargs):
     """Wrap for gradient synchronisation when more than one rank runs; otherwise return the
     module unchanged, so single-process checkpoints have no ``module.`` prefix
@@ -103,7 +105,7 @@ def prepare_ddp_model(model, device_ids, *args, **kwargs):
     return model
 
 
-# synchronization functions
+# ---- collectives
 def all_reduce(tensor, op='sum'):
     """In-place all-reduce with a string op, ``'sum'`` or ``'avg'``; returns the same tensor
     (reference distributed.py:119-133).  ``'avg'`` divides in place, so it needs a float tensor."""
@@ -137,7 +139,7 @@ def gather(data):
 
 def sync_params(params):
     """
-    Synchronize a sequence of Tensors across ranks from rank 0.
+    Overwrite every tensor of ``params`` with rank 0's copy.
     """
     if is_dist_avail_and_initialized():
         with torch.no_grad():
@@ -151,7 +153,7 @@ def barrier():
     _pg.barrier()
 
 
-# wrapper with same functionality but better readability as barrier
+# alias of barrier() kept for the reference's call sites
 def wait_for_everyone():
     barrier()
 

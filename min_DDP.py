@@ -92,7 +92,7 @@ def train(model, loader, criterion, optimizer, args):
             meter.update(loss, correct)
             continue
 
-        # metrics per gpu/process
+        # this rank's own numbers
         print(f"Device: {x.device}"
               f"\n\tInput: \t{x.squeeze().to(torch.uint8)}"
               f"\n\tLabel: \t{y.squeeze()}"
@@ -101,16 +101,16 @@ def train(model, loader, criterion, optimizer, args):
               f"\n\tAcc:   \t{correct.sum() / n:.5f} ({correct.sum()}/{n})"
               f"\n\tLoss:  \t{loss.cpu().item():.5f}")
 
-        # wait until all processes are at this point
+        # line the ranks up so the per-rank blocks above are not interleaved with the summary
         dist.wait_for_everyone()
 
-        # synchronize metrics across gpus/processes
+        # combine over ranks: SUM of the losses to rank 0 (as the reference does), gather of the hit masks
         loss = dist.reduce(loss.detach().clone())       # SUM over ranks, valid on the primary
         correct = dist.gather(correct.detach())         # all ranks' flags, valid on the primary
         correct = torch.cat(correct, dim=0)
         acc = correct.sum() / correct.numel()
 
-        # metrics over all gpus, printed only on the main process
+        # job-wide line, primary rank only
         dist.print_primary(f"Finish iteration {it}"
                            f" - acc: {acc.cpu().item():.4f} ({correct.sum()}/{correct.shape[0]})"
                            f" - loss: {loss.cpu().item():.4f}")
@@ -121,7 +121,7 @@ def train(model, loader, criterion, optimizer, args):
                            f" - loss (sum over ranks, mean over iterations): {mean_loss_sum:.4f}")
 
 
-# Main workers ##################
+# ---------------------------------------------------------------- worker
 def main_worker(gpu, world_size, argv=None):
     is_distributed = world_size > 1
     args = parse_args(argv)
@@ -142,12 +142,12 @@ def main_worker(gpu, world_size, argv=None):
     loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=(sampler is None), sampler=sampler,
                         pin_memory=False)  # DevicePrefetcher stages through its own pinned ring
 
-    """ Model """
+    # model
     model = DummyModel(in_dim=1, hidden_dim=args.hidden_dim, n_classes=args.n_classes, native=native)
     model.to(device)
     model = dist.prepare_ddp_model(model, device_ids=[gpu])
 
-    """ Optimizer and Loss """
+    # optimizer and loss
     if native:
         optimizer = FusedAdamW(model.parameters(), 0.0001)
         criterion = SoftmaxCrossEntropy()
@@ -155,7 +155,7 @@ def main_worker(gpu, world_size, argv=None):
         optimizer = torch.optim.AdamW(model.parameters(), 0.0001)
         criterion = nn.CrossEntropyLoss()
 
-    """ Run Epochs """
+    # epochs
     print("Run epochs")
     t0 = time.perf_counter()
     for epoch in range(args.epochs):
@@ -168,7 +168,7 @@ def main_worker(gpu, world_size, argv=None):
     if args.quiet:
         dist.print_primary(f"Wall time: {time.perf_counter() - t0:.3f} s")
 
-    # kill process group
+    # leave the job
     dist.cleanup()
 
 

@@ -284,3 +284,19 @@ def test_rccl_group_through_torch_distributed_run_store():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "rccl over the launcher store ok: world 1" in out.stdout
+
+
+def test_bounded_host_waits_of_the_communicator():
+    """DIST_WATCHDOG_S: barrier / slot reuse / stream synchronisation work under a generous limit and raise
+    an error that names rank and operation when the wait outlasts the limit."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    probe = os.path.join(root, "tools", "watchdog_probe.py")
+    ok = subprocess.run([sys.executable, probe, "ok"], capture_output=True, text=True, timeout=150, env=env, cwd=root)
+    assert ok.returncode == 0 and "watchdog ok: async 20" in ok.stdout, ok.stdout[-1000:] + ok.stderr[-2000:]
+    stall = subprocess.run([sys.executable, probe, "stall"], capture_output=True, text=True, timeout=150, env=env, cwd=root)
+    assert stall.returncode == 0, stall.stderr[-2000:]
+    assert "raised: collective watchdog [rank 0/1, GPU 0]: barrier did not finish" in stall.stdout, stall.stdout

@@ -118,7 +118,9 @@ void RcclComm::wait_stream_bounded(hipStream_t s, const char* what) {
   const auto t0 = std::chrono::steady_clock::now();
   int us = 20;
   for (;;) {
-    if (s != current_stream(device_)) (void)hipStreamQuery(current_stream(device_));  // see wait_event_bounded
+    // a query also hands the stream's batched commands to the hardware: `s` may be waiting for a fence
+    // recorded on the current stream
+    if (s != current_stream(device_)) (void)hipStreamQuery(current_stream(device_));
     const hipError_t q = hipStreamQuery(s);
     if (q == hipSuccess) return;
     if (q != hipErrorNotReady) DPA_HIP_CHECK(q);

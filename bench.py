@@ -50,6 +50,7 @@ def parse_args(argv=None):
     p.add_argument("--no-fuse-add-norm", action="store_true", help="GPT-2: separate residual adds and layer norms (ablation)")
     p.add_argument("--reduce-dtype", default=None, choices=["fp32", "bf16"], help="gradient all-reduce dtype")
     p.add_argument("--bucket-mb", type=float, default=None)
+    p.add_argument("--no-busbw", action="store_true", help="skip the all-reduce bus-bandwidth measurement after the timed steps (N > 1)")
     p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
     p.add_argument("--stock", action="store_true", help="comparison run: stock torch ops and torch.optim.AdamW(fused=True)")
     p.add_argument("--tuned-gemms", action="store_true", help="vendor GEMMs by the shipped TunableOp solution table instead of the library's default heuristic (measured: within 0.5 %% of the default)")
@@ -247,6 +248,13 @@ def run_rank(rank: int, world_size: int, argv):
         "final_loss": round(final_loss, 5),
         "first_loss": round(float(first_loss.detach().float().item()), 5) if first_loss is not None else None,
     }
+    if world_size > 1 and use_gpu and pg.get_backend() == "rccl" and not args.no_busbw:
+        # After the timed region: all-reduce bus bandwidth at the reducer's bucket size and at 256 MiB, on the
+        # reducer's own path (communication stream + event fences).  Never allowed to cost the result line.
+        try:
+            result["allreduce_busbw_gbps"] = _allreduce_busbw(pg, dist, device, world_size)
+        except Exception as exc:  # noqa: BLE001 - diagnostic extra only
+            result["allreduce_busbw_gbps"] = f"failed: {type(exc).__name__}: {exc}"
     if use_gpu:
         result["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
         result["peak_reserved_gb"] = round(torch.cuda.max_memory_reserved(device) / 2**30, 2)
@@ -257,6 +265,35 @@ def run_rank(rank: int, world_size: int, argv):
             Path(args.json_out).parent.mkdir(parents=True, exist_ok=True)
             Path(args.json_out).write_text(line + "\n")
     dist.cleanup()
+
+
+def _allreduce_busbw(pg, dist, device, world_size, sizes_mb=(64, 256), iters=10):
+    """Bus bandwidth (GB/s, 2(N-1)/N * bytes / time) of bf16 all-reduces of the given sizes."""
+    import torch
+
+    from distributed_pytorch_amd.utils.timer import allreduce_bus_bandwidth_gbps
+
+    comm = pg.get_comm()
+    out = {}
+    for mb in sizes_mb:
+        t = torch.ones((mb << 20) // 2, dtype=torch.bfloat16, device=device)
+        for _ in range(2):
+            comm.all_reduce_async(t, pg.OP_AVG, 0)
+            comm.wait_slot(0)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            comm.all_reduce_async(t, pg.OP_AVG, 0)
+            comm.wait_slot(0)
+        e.record()
+        e.synchronize()
+        sec = torch.tensor([s.elapsed_time(e) / 1e3 / iters], dtype=torch.float64, device=device)
+        pg.all_reduce(sec, "max")
+        out[f"{mb}MiB"] = round(allreduce_bus_bandwidth_gbps(mb << 20, float(sec.item()), world_size), 1)
+        del t
+    return out
 
 
 def _spawned_worker(rank, world_size, argv):

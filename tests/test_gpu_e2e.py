@@ -286,6 +286,23 @@ def test_rccl_group_through_torch_distributed_run_store():
     assert "rccl over the launcher store ok: world 1" in out.stdout
 
 
+def test_bench_bus_bandwidth_probe_runs_on_the_reducer_path(rccl_group):
+    """The post-run all-reduce bandwidth measurement of bench.py (only taken with N > 1): same calls at
+    world size 1, where the formula's 2(N-1)/N factor makes the result zero."""
+    import importlib.util
+
+    import distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n0 = rccl_group.get_comm().num_async_ops()
+    out = bench._allreduce_busbw(rccl_group, dist, torch.device("cuda", 0), 1, sizes_mb=(1, 4), iters=3)
+    assert out == {"1MiB": 0.0, "4MiB": 0.0}
+    assert rccl_group.get_comm().num_async_ops() == n0 + 2 * (2 + 3)
+
+
 def test_bounded_host_waits_of_the_communicator():
     """DIST_WATCHDOG_S: barrier / slot reuse / stream synchronisation work under a generous limit and raise
     an error that names rank and operation when the wait outlasts the limit."""

@@ -42,7 +42,6 @@ PYBIND11_MODULE(_C, m) {
       .def("group_start", &RcclComm::group_start)
       .def("group_end", &RcclComm::group_end)
       .def("num_async_ops", &RcclComm::num_async_ops)
-      .def("watchdog_seconds", &RcclComm::watchdog_seconds)
       .def("destroy", &RcclComm::destroy, py::call_guard<py::gil_scoped_release>())
       .def("abort", &RcclComm::abort);
 

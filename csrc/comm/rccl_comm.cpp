@@ -2,12 +2,9 @@
 
 #include <c10/hip/HIPStream.h>
 
-#include <chrono>
-#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
-#include <thread>
 
 namespace dpa {
 
@@ -88,47 +85,6 @@ RcclComm::RcclComm(const std::string& uid, int rank, int world, int device)
   ensure_comm_stream();
   DPA_NCCL_CHECK(ncclCommInitRank(&comm_, world_, id, rank_));
   barrier_scratch_ = at::zeros({1}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, device_));
-  if (const char* e = std::getenv("DIST_WATCHDOG_S")) wd_limit_s_ = std::atof(e);
-}
-
-void RcclComm::watchdog_timeout(const char* what, double waited) const {
-  std::ostringstream os;
-  os << "collective watchdog [rank " << rank_ << "/" << world_ << ", GPU " << device_ << "]: " << what << " did not finish within "
-     << waited << " s (DIST_WATCHDOG_S=" << wd_limit_s_ << "); a peer has probably left the job";
-  throw std::runtime_error(os.str());
-}
-
-// Host waits: blocking without a limit, polling (with back-off up to 1 ms) when a limit is set.  With a
-// limit the wait for one slot's completion event becomes a wait for the whole communication stream:
-// hipEventQuery on these events stayed "not ready" for good on this runtime (ROCm 7.0) although
-// hipEventSynchronize on the same event returns at once, while hipStreamQuery reports faithfully.
-void RcclComm::wait_event_bounded(hipEvent_t e, const char* what) {
-  if (wd_limit_s_ <= 0.0) {
-    DPA_HIP_CHECK(hipEventSynchronize(e));
-    return;
-  }
-  wait_stream_bounded(comm_stream_, what);
-}
-
-void RcclComm::wait_stream_bounded(hipStream_t s, const char* what) {
-  if (wd_limit_s_ <= 0.0) {
-    DPA_HIP_CHECK(hipStreamSynchronize(s));
-    return;
-  }
-  const auto t0 = std::chrono::steady_clock::now();
-  int us = 20;
-  for (;;) {
-    // a query also hands the stream's batched commands to the hardware: `s` may be waiting for a fence
-    // recorded on the current stream
-    if (s != current_stream(device_)) (void)hipStreamQuery(current_stream(device_));
-    const hipError_t q = hipStreamQuery(s);
-    if (q == hipSuccess) return;
-    if (q != hipErrorNotReady) DPA_HIP_CHECK(q);
-    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (waited > wd_limit_s_) watchdog_timeout(what, waited);
-    std::this_thread::sleep_for(std::chrono::microseconds(us));
-    if (us < 1000) us *= 2;
-  }
 }
 
 RcclComm::~RcclComm() {
@@ -237,7 +193,7 @@ void RcclComm::barrier() {
   DeviceGuard g(device_);
   hipStream_t s = current_stream(device_);
   DPA_NCCL_CHECK(ncclAllReduce(barrier_scratch_.data_ptr(), barrier_scratch_.data_ptr(), 1, ncclFloat32, ncclSum, comm_, s));
-  wait_stream_bounded(s, "barrier");
+  DPA_HIP_CHECK(hipStreamSynchronize(s));
 }
 
 // Prepares slot `slot` for a new operation: events exist, and a previous operation on the same
@@ -264,7 +220,7 @@ void RcclComm::begin_slot(int slot) {
   }
   if (!slot_events_[s]) DPA_HIP_CHECK(hipEventCreateWithFlags(&slot_events_[s], hipEventDisableTiming));
   if (!fence_events_[s]) DPA_HIP_CHECK(hipEventCreateWithFlags(&fence_events_[s], hipEventDisableTiming));
-  if (slot_pending_[s]) wait_event_bounded(slot_events_[s], "the previous collective of a gradient-bucket slot");
+  if (slot_pending_[s]) DPA_HIP_CHECK(hipEventSynchronize(slot_events_[s]));
 }
 
 void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
@@ -311,7 +267,7 @@ void RcclComm::wait_all_slots() {
 
 void RcclComm::synchronize_comm_stream() {
   DeviceGuard g(device_);
-  if (comm_stream_) wait_stream_bounded(comm_stream_, "the communication stream");
+  if (comm_stream_) DPA_HIP_CHECK(hipStreamSynchronize(comm_stream_));
 }
 
 void RcclComm::group_start() { DPA_NCCL_CHECK(ncclGroupStart()); }

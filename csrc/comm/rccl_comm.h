@@ -9,12 +9,6 @@
 //   * metric-sized collectives (reduce / gather / barrier) are issued on the current stream,
 //     where a dependency on the preceding kernels already exists, so they cost no fences;
 //   * gather uses RCCL's native ncclGather instead of grouped send/recv.
-//   * with DIST_WATCHDOG_S=<seconds> every host-side wait of this class (barrier, reuse of a bucket
-//     slot, synchronisation of the communication stream) polls with that limit and raises an error
-//     naming rank and operation instead of blocking forever when a peer has gone away.  The polling is
-//     done by the calling thread: a separate watchdog thread that queried completion events (the way
-//     NCCL-based stacks do it) was tried and made the collectives themselves stall on this runtime,
-//     the same class of hazard as streams created after the communicator.
 // xGMI peer-to-peer is left enabled (the reference disables P2P, distributed.py:47).
 #pragma once
 
@@ -73,15 +67,11 @@ class RcclComm {
 
   // Timing of the last bucket collectives, for the bus-bandwidth report.
   int64_t num_async_ops() const { return n_async_; }
-  double watchdog_seconds() const { return wd_limit_s_; }  // 0: host waits block without limit
 
  private:
   void begin_slot(int slot);
   void ensure_comm_stream();
   void check_tensor(const at::Tensor& t) const;
-  void wait_event_bounded(hipEvent_t e, const char* what);
-  void wait_stream_bounded(hipStream_t s, const char* what);
-  [[noreturn]] void watchdog_timeout(const char* what, double waited) const;
 
   ncclComm_t comm_ = nullptr;
   int rank_, world_, device_;
@@ -92,7 +82,6 @@ class RcclComm {
   at::Tensor barrier_scratch_;
   int64_t n_async_ = 0;
   bool destroyed_ = false;
-  double wd_limit_s_ = 0.0;
 };
 
 ncclDataType_t to_nccl_dtype(at::ScalarType t);

@@ -301,19 +301,3 @@ def test_bench_bus_bandwidth_probe_runs_on_the_reducer_path(rccl_group):
     out = bench._allreduce_busbw(rccl_group, dist, torch.device("cuda", 0), 1, sizes_mb=(1, 4), iters=3)
     assert out == {"1MiB": 0.0, "4MiB": 0.0}
     assert rccl_group.get_comm().num_async_ops() == n0 + 2 * (2 + 3)
-
-
-def test_bounded_host_waits_of_the_communicator():
-    """DIST_WATCHDOG_S: barrier / slot reuse / stream synchronisation work under a generous limit and raise
-    an error that names rank and operation when the wait outlasts the limit."""
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    probe = os.path.join(root, "tools", "watchdog_probe.py")
-    ok = subprocess.run([sys.executable, probe, "ok"], capture_output=True, text=True, timeout=150, env=env, cwd=root)
-    assert ok.returncode == 0 and "watchdog ok: async 20" in ok.stdout, ok.stdout[-1000:] + ok.stderr[-2000:]
-    stall = subprocess.run([sys.executable, probe, "stall"], capture_output=True, text=True, timeout=150, env=env, cwd=root)
-    assert stall.returncode == 0, stall.stderr[-2000:]
-    assert "raised: collective watchdog [rank 0/1, GPU 0]: barrier did not finish" in stall.stdout, stall.stdout

@@ -217,19 +217,50 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
 //     moves ~79 B/clk/CU, less than a third of the read rate);
 //   * the DMA writes LDS linearly (wave base + lane*16), so the bank-conflict swizzle is applied
 //     to each lane's GLOBAL source address, and the same XOR is applied when fragments are read;
-//   * two LDS buffers (2 x 64 KiB, one workgroup per CU): the DMA of tile k+1 is issued right
-//     after the barrier that publishes tile k and lands while tile k is being multiplied;
+//   * a k-step of an operand is staged as two HALF-TILES of 128 rows x 64 k (16 KiB, two DMA
+//     instructions per wave).  Half h of A holds rows wr*128 + h*64 .. +63 of both wave rows wr,
+//     half h of B holds rows wc*64 + h*32 .. +31 of all four wave columns wc, so every wave reads
+//     each half-tile in exactly one of the four phases of a k-step and the half-tile can be
+//     restaged two phases later;
+//   * two k-steps of LDS (2 x 64 KiB, one workgroup per CU).  Half-tiles are requested in the order
+//     B0 A0 B1 A1, one per phase, three half-tiles (six DMA instructions per wave) stay in flight
+//     across the barriers: the only wait inside the loop is one counted s_waitcnt vmcnt(6) per k-step;
+//   * a k-step is four phases of 16 MFMAs (one quadrant of the wave's tile: 64 rows x 32 columns x
+//     64 k); each phase is {fragment reads + one half-tile request | barrier | MFMAs | barrier}, and
+//     the upper wave row runs one barrier behind the lower one, so on every SIMD one wave issues
+//     MFMAs while its partner reads LDS and requests memory;
 //   * rows / columns past the matrix edge are clamped to the last valid one (their results are
 //     never stored); K must be a multiple of 64 (no zero fill exists on the DMA path).
 // =====================================================================================
+// Diagnostic builds only (tools/kernel_harness, -DDPA_GEMM_STAMPS): wave 0 of every workgroup records
+// the shader clock at a few points into p.colsum_partial (unused by the plain product).
+#ifdef DPA_GEMM_STAMPS
+#define DPA_STAMP(i)                                                                                         \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    unsigned long long t_;                                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.colsum_partial)[blockIdx.x * 8 + (i)] = t_; \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+#else
+#define DPA_STAMP(i)
+#endif
+
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int kThreads2 = 512;
-constexpr int kTileBytes2 = BM2 * BK2 * 2;  // 32 KiB per operand per stage
+constexpr int kTileBytes2 = BM2 * BK2 * 2;  // 32 KiB per operand per k-step
+constexpr int kHalfBytes = 128 * BK2 * 2;   // 16 KiB: one half-tile
+// position of the half-tiles inside a k-step's 64 KiB, in request order
+constexpr int kHalfB0 = 0, kHalfA0 = 1, kHalfB1 = 2, kHalfA1 = 3;
 
-// [256 rows][64 k] image, 128-byte rows: same chunk swizzle as the small kernel.
+// [128 local rows][64 k] image, 128-byte rows, 16-byte chunks XOR-swizzled by (row>>1)&7: the 16
+// lanes a ds_read_b128 serves per LDS cycle (rows 0-3 and 12-15 at one chunk, rows 4-11 at the next)
+// then fall on 16 different 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int kmajor2_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
-// [64 k][256 rows] image, 512-byte rows, 32 chunks: XOR on the low four chunk bits.
-__device__ __forceinline__ int rmajor2_off(int k, int c) { return k * 512 + ((c ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)))) << 4); }
+// [64 k][128 local rows] image, 256-byte rows (one bank row each), 16 chunks: the eight k-rows a
+// 32-lane half of a transposing read touches (q and 8+q, q = 0..3) get eight different 32-byte slots.
+__device__ __forceinline__ int rmajor2_off(int k, int c) { return k * 256 + ((c ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)))) << 4); }
 
 // GELU'(x) of a bf16 x only takes 65536 values, and outside 2^-12 <= |x| < 8 it is 0.5, 0 or 1 to well
 // below bf16 resolution (likewise Phi(x) for the forward, GELU(x) = x * Phi(x)): the epilogues look it up in an LDS table
@@ -243,31 +274,36 @@ constexpr int kGeluTableBytes = 2 * kGeluEntries * 4;
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-// This wave's share of one operand tile is 4 DMA instructions of 1 KiB each.  Their per-lane source
-// addresses are split into a wave-uniform 64-bit base that moves with the k-step (kept in SGPRs,
-// advanced by scalar adds) and a per-lane 32-bit byte offset inside the tile's rows that never
-// changes, computed once here: the loop body then spends no vector registers or VALU work on
-// addresses.  Offsets stay far below 4 GiB because they are relative to the tile (256 rows at most
-// for a k-contiguous operand, 64 k-rows otherwise), not to the matrix.
-template <bool KMAJOR>
-__device__ __forceinline__ void dma_offsets(long long ld, long long r0, long long R, int wid, int lane, unsigned (&off)[4]) {
+// This wave's share of one half-tile is 2 DMA instructions of 1 KiB each (pieces 2*wave, 2*wave+1 of
+// 16).  Their per-lane source addresses are split into a wave-uniform 64-bit base that moves with
+// the k-step (kept in SGPRs, advanced by scalar adds) and a per-lane 32-bit byte offset inside the
+// tile's rows that never changes, computed once here: the loop body then spends no vector registers
+// or VALU work on addresses.  Offsets stay far below 4 GiB because they are relative to the tile
+// (256 rows at most for a k-contiguous operand, 64 k-rows otherwise), not to the matrix.
+// SPAN = rows one wave row / column owns inside a half-tile (64 for A, 32 for B); the same wave
+// row / column owns 2*SPAN consecutive rows of the full tile.
+template <bool KMAJOR, int SPAN>
+__device__ __forceinline__ void dma_offsets(long long ld, long long r0, long long R, int wid, int lane, unsigned (&off)[2][2]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wid * 4 + i;  // 32 pieces of 1 KiB per tile
-    if (KMAJOR) {
-      const int row = piece * 8 + (lane >> 3);                  // 8 rows of 128 B per piece
-      const int c = (lane & 7) ^ ((row >> 1) & 7);              // logical chunk that belongs at this physical slot
-      long long gr = r0 + row;
-      gr = gr < R ? gr : R - 1;                                 // rows past the edge re-read the last row
-      off[i] = static_cast<unsigned>(((gr - r0) * ld + c * 8) * 2);
-    } else {
-      const int k = piece * 2 + (lane >> 5);                    // 2 k-rows of 512 B per piece
-      const int c = (lane & 31) ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)));
-      long long gc = r0 + c * 8;
-      gc = gc + 8 <= R ? gc : (R - 8);                          // R % 8 == 0 is required by the dispatcher
-      off[i] = static_cast<unsigned>((k * ld + (gc - r0)) * 2);
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wid * 2 + i;  // 16 pieces of 1 KiB per half-tile
+      if (KMAJOR) {
+        const int lr = piece * 8 + (lane >> 3);                   // 8 local rows of 128 B per piece
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);               // logical chunk that belongs at this physical slot
+        long long gr = r0 + (lr / SPAN) * (2 * SPAN) + h * SPAN + lr % SPAN;
+        gr = gr < R ? gr : R - 1;                                 // rows past the edge re-read the last row
+        off[h][i] = static_cast<unsigned>(((gr - r0) * ld + c * 8) * 2);
+      } else {
+        const int k = piece * 4 + (lane >> 4);                    // 4 k-rows of 256 B per piece
+        const int c = (lane & 15) ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)));
+        const int lr = c * 8;                                     // first of the chunk's 8 local rows
+        long long gc = r0 + (lr / SPAN) * (2 * SPAN) + h * SPAN + lr % SPAN;
+        gc = gc + 8 <= R ? gc : (R - 8);                          // R % 8 == 0 is required by the dispatcher
+        off[h][i] = static_cast<unsigned>((k * ld + (gc - r0)) * 2);
+      }
     }
-  }
 }
 // Base of the tile for k-step starting at k0 (wave-uniform).
 template <bool KMAJOR>
@@ -287,12 +323,12 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
   const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
   return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
-__device__ __forceinline__ void dma_issue(const char* base_in, const unsigned (&off)[4], char* lds_tile, int wid) {
+__device__ __forceinline__ void dma_issue(const char* base_in, const unsigned (&off)[2], char* lds_half, int wid) {
   const char* base = uniform_ptr(base_in);
   const unsigned dst0 = __builtin_amdgcn_readfirstlane(
-      static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)(lds_tile + wid * 4096))));
+      static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)(lds_half + wid * 2048))));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const unsigned dst = dst0 + i * 1024;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off[i]), "s"(base), "s"(dst) : "memory");
   }
@@ -319,8 +355,9 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int tile_row0, int
 // SPLIT: blockIdx.y selects a contraction range of `k_iters` steps; raw fp32 partial tiles go to
 // p.workspace[blockIdx.y][M][N] (16-byte stores) and splitk_reduce_kernel finishes the product.
 template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT>
-__global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters) {
-  extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 stages][A tile | B tile][GELU' table]
+__global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 k-steps][B0 | A0 | B1 | A1][GELU' table]
+  DPA_STAMP(0);
 
   float* gelu_tab = reinterpret_cast<float*>(smem2 + 4 * kTileBytes2);
   if (!SPLIT && (p.aux_mode == kActGelu || p.act == kActGelu)) {
@@ -363,61 +400,34 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
 
   const long long nk_all = p.K / BK2;
   const long long kt0 = SPLIT ? static_cast<long long>(blockIdx.y) * k_iters : 0;
-  const long long nk = SPLIT ? (kt0 + k_iters < nk_all ? kt0 + k_iters : nk_all) : nk_all;
-  // One k-step per barrier: every wave waits for its own DMA pieces of tile kt, the barrier publishes
-  // the tile (and retires all reads of the other stage), tile kt+1 is requested into the other
-  // stage, then all 24 fragment reads of the step are issued in one burst ahead of its 64 MFMAs (the
-  // scheduler would otherwise sink each read next to its first use and expose the LDS latency in
-  // front of every group of four MFMAs).  A phase-shifted schedule (wave groups alternating between
-  // reading and multiplying) and per-half fragment double buffering were measured on 8192^3 and on
-  // the GPT-2 shapes and came out 3-10 % slower than this arrangement.  Timing variants of this loop
-  // on 8192^3 (harness, uniform random operands, 1.14 PFLOP/s as is): every request re-reading one
-  // L2-resident k-tile 1.21, no requests at all 1.38, no barrier 1.21, neither 1.45 -- the LDS-DMA
-  // traffic itself (64 KiB of LDS writes per k-step next to 192 KiB of fragment reads) costs more than
-  // memory latency or the barrier.  Moving the barrier and the next step's first fragment reads into
-  // the middle of the MFMA stream (so that no MFMA ever waits on LDS latency) changed nothing, and a
-  // 4-wave variant with 128 x 128 per wave (512 registers, a third less LDS read traffic) fell to
-  // 0.88: with one wave per SIMD nothing covers the read bursts unless reads and MFMAs are interleaved
-  // instruction by instruction, which the compiler does not do.
-  bf16x8 fa[2][8], fb[2][4];
-  auto read_frags = [&](int stage) {
-    const char* as = smem2 + stage * 2 * kTileBytes2;
-    const char* bs = as + kTileBytes2;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[kk][j] = read_frag2<B_KMAJOR>(bs, wn + 16 * j, kk, lane);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fa[kk][i] = read_frag2<A_KMAJOR>(as, wm + 16 * i, kk, lane);
-    }
-  };
-  auto multiply = [&]() {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
-  };
-  unsigned off_a[4], off_b[4];
-  dma_offsets<A_KMAJOR>(p.lda, m0, p.M, wid, lane, off_a);
-  dma_offsets<B_KMAJOR>(p.ldb, n0, p.N, wid, lane, off_b);
-  auto request = [&](long long kt, int stage) {
-    char* dst = smem2 + stage * 2 * kTileBytes2;
-    dma_issue(dma_base<A_KMAJOR>(A, p.lda, m0, kt * BK2), off_a, dst, wid);
-    dma_issue(dma_base<B_KMAJOR>(B, p.ldb, n0, kt * BK2), off_b, dst + kTileBytes2, wid);
+  const long long nk_end = SPLIT ? (kt0 + k_iters < nk_all ? kt0 + k_iters : nk_all) : nk_all;
+  const int n = static_cast<int>(nk_end - kt0);  // k-steps of this workgroup
+  const int wr = wid >> 2, wc = wid & 3;
+
+  unsigned off_a[2][2], off_b[2][2];
+  dma_offsets<A_KMAJOR, 64>(p.lda, m0, p.M, wid, lane, off_a);
+  dma_offsets<B_KMAJOR, 32>(p.ldb, n0, p.N, wid, lane, off_b);
+  // Request half-tile `which` (kHalfB0 .. kHalfA1) of this workgroup's k-step t into LDS buffer buf.
+  auto request = [&](int which, int t, int buf) __attribute__((always_inline)) {
+    char* dst = smem2 + buf * 2 * kTileBytes2 + which * kHalfBytes;
+    if (which & 1) dma_issue(dma_base<A_KMAJOR>(A, p.lda, m0, (kt0 + t) * BK2), off_a[which >> 1], dst, wid);
+    else dma_issue(dma_base<B_KMAJOR>(B, p.ldb, n0, (kt0 + t) * BK2), off_b[which >> 1], dst, wid);
   };
   // nothing may be scheduled across the barrier
-  auto phase_barrier = [&]() {
+  auto phase_barrier = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  auto lds_reads_done = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
   // Activation-backward epilogue only: the aux tile is fetched by LDS-DMA as well, each wave's 128 x 64
-  // piece in two halves of 64 rows x 128 B (8 KiB, 8 instructions) at  stage * 64 KiB + wave * 8 KiB.
-  // The first half goes into the stage that the last k-step leaves idle, so its latency hides behind
-  // that step's MFMAs; the second half follows once the operand stages are dead.  LDS position
+  // piece in two halves of 64 rows x 128 B (8 KiB, 8 instructions) at  buffer * 64 KiB + wave * 8 KiB.
+  // The first half goes into the buffer that the last k-step leaves idle, so its latency hides behind
+  // that step's MFMAs; the second half follows once the operand buffers are dead.  LDS position
   // (lane & 7) of row (lane >> 3) receives chunk (lane & 7) ^ (lane >> 3) of the row (XOR on the
   // source address), which spreads the accumulator-layout reads of the epilogue over the banks.
   const bool act_bwd = !SPLIT && p.aux_mode != kActNone;
@@ -434,17 +444,111 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
     }
   };
 
-  request(kt0, 0);
-  for (long long kt = kt0; kt < nk; ++kt) {
-    const int cur = static_cast<int>((kt - kt0) & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    phase_barrier();
-    if (kt + 1 < nk) request(kt + 1, cur ^ 1);
-    else if (act_bwd) aux_request(0, cur ^ 1);
-    read_frags(cur);
+  // Fragment registers: the A fragments of one 64-row half (reloaded in phase 3), the B fragments of
+  // both 32-column halves (kept for the whole k-step: B0 is used again in phase 4).
+  bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+  auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
+    const char* img = smem2 + buf * 2 * kTileBytes2 + (h ? kHalfA1 : kHalfA0) * kHalfBytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag2<A_KMAJOR>(img, wr * 64 + 16 * i, kk, lane);
+  };
+  auto read_b = [&](int buf, int h, bf16x8 (&fb)[2][2]) __attribute__((always_inline)) {
+    const char* img = smem2 + buf * 2 * kTileBytes2 + (h ? kHalfB1 : kHalfB0) * kHalfBytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[kk][j] = read_frag2<B_KMAJOR>(img, wc * 32 + 16 * j, kk, lane);
+  };
+  // 16 MFMAs: quadrant (row half ah, column half bh) of the wave's tile over the whole k-step
+  auto multiply = [&](int ah, int bh, const bf16x8 (&fb)[2][2]) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 * ah + i][2 * bh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[4 * ah + i][2 * bh + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // One k-step = four phases.  Request order and the reads' phases make every restage safe without
+  // extra waits (t = k-step being multiplied out of buffer buf; "retired" = the reads' data is in
+  // registers on every wave, which the barriers between guarantee):
+  //   phase 1  reads B0 (retired before the phase's first barrier: lgkmcnt(8)) and A0   requests A1 of t+1 -> other buffer
+  //   phase 2  reads B1                                                                 requests B0 of t+2 -> this buffer
+  //   phase 3  reads A1                                                                 requests A0 of t+2
+  //   phase 4  (B0 still in registers)                                                  requests B1 of t+2, waits vmcnt(6)
+  // A half-tile is requested again at the earliest two phases after its last read (B0: one phase, after
+  // the early wait), and the vmcnt(6) of phase 4 -- everything but the three newest half-tiles has
+  // landed, i.e. all of k-step t+1 -- is followed by two barriers before phase 1 of t+1 reads it.
+  auto k_step = [&](int t, auto buf_c) __attribute__((always_inline)) {
+    constexpr int buf = decltype(buf_c)::value;
+    const bool next1 = t + 1 < n, next2 = t + 2 < n;
+    // phase 1
+    read_b(buf, 0, fb0);
     __builtin_amdgcn_sched_barrier(0);
-    multiply();
+    read_a(buf, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (next1) request(kHalfA1, t + 1, buf ^ 1);
+    else if (act_bwd) aux_request(0, buf ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    phase_barrier();
+    lds_reads_done();
+    multiply(0, 0, fb0);
+    phase_barrier();
+    // phase 2
+    read_b(buf, 1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (next2) request(kHalfB0, t + 2, buf);
+    phase_barrier();
+    lds_reads_done();
+    multiply(0, 1, fb1);
+    phase_barrier();
+    // phase 3
+    read_a(buf, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (next2) request(kHalfA0, t + 2, buf);
+    phase_barrier();
+    lds_reads_done();
+    multiply(1, 1, fb1);
+    phase_barrier();
+    // phase 4
+    if (next2) {
+      request(kHalfB1, t + 2, buf);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (next1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    phase_barrier();
+    multiply(1, 0, fb0);
+    phase_barrier();
+  };
+
+  // prologue: all of k-step 0 and three half-tiles of k-step 1
+  request(kHalfB0, 0, 0);
+  request(kHalfA0, 0, 0);
+  request(kHalfB1, 0, 0);
+  request(kHalfA1, 0, 0);
+  if (n > 1) {
+    request(kHalfB0, 1, 1);
+    request(kHalfA0, 1, 1);
+    request(kHalfB1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  phase_barrier();
+  DPA_STAMP(1);
+  if (wr == 1) phase_barrier();  // the upper wave row runs one barrier behind
+  for (int t = 0; t < n; t += 2) {
+    k_step(t, std::integral_constant<int, 0>{});
+    if (t + 1 < n) k_step(t + 1, std::integral_constant<int, 1>{});
+  }
+  if (wr == 0) phase_barrier();
+  DPA_STAMP(2);
   if (SPLIT) {
     float* ws = p.workspace + static_cast<long long>(blockIdx.y) * p.M * p.N;
 #pragma unroll
@@ -531,7 +635,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
       // that sit under its accumulators out of the DMA image, writes the result back into the same
       // cells, and the rows then leave as 8 rows x 128 contiguous bytes per store instruction -- so
       // neither direction touches global memory with the accumulator layout's 32-byte row pieces.
-      const int last = static_cast<int>((nk - 1 - kt0) & 1);  // stage of the last k-step; half 0 sits in the other one
+      const int last = (n - 1) & 1;  // stage of the last k-step; half 0 sits in the other one
       aux_request(1, last);
       u16* Cout = static_cast<u16*>(p.C);
       float csum = 0.f;  // lane c: column n0 + wn + c of this wave's 128 rows
@@ -599,6 +703,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_v2_kernel(GemmArgs p, 
     if (p.act == kActGelu) emit_all(std::integral_constant<int, kActGelu>{});
     else if (p.act == kActRelu) emit_all(std::integral_constant<int, kActRelu>{});
     else emit_all(std::integral_constant<int, kActNone>{});
+    DPA_STAMP(3);
     return;
   }
 #pragma unroll
@@ -702,18 +807,18 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
       constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
       static bool configured = false;
       if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes2 + kGeluTableBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_v2_kernel<AK, BKM, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes2 + kGeluTableBytes);
         configured = true;
       }
       if (split) {
-        hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKM, true>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, true>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
         const long long quads = a.M * (a.N >> 2);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, stream, a);
       } else {
-        hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKM, false>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, false>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
       }
     };
     if (a.a_kmajor && a.b_kmajor) go2(std::true_type{}, std::true_type{});

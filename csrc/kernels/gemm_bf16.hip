@@ -243,8 +243,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
     if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.colsum_partial)[blockIdx.x * 8 + (i)] = t_; \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   } while (0)
+#define DPA_STAMP_REAL(i)                                                                                    \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    unsigned long long t_;                                                                                   \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.colsum_partial)[blockIdx.x * 8 + (i)] = t_; \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
 #else
 #define DPA_STAMP(i)
+#define DPA_STAMP_REAL(i)
 #endif
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
@@ -323,43 +332,91 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
   const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
   return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
-__device__ __forceinline__ void dma_issue(const char* base_in, const unsigned (&off)[2], char* lds_half, int wid) {
-  const char* base = uniform_ptr(base_in);
-  const unsigned dst0 = __builtin_amdgcn_readfirstlane(
-      static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)(lds_half + wid * 2048))));
+__device__ __forceinline__ void dma_issue(const char* base, const unsigned (&off)[2], unsigned lds_dst) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const unsigned dst = dst0 + i * 1024;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off[i]), "s"(base), "s"(dst) : "memory");
+    const unsigned dst = lds_dst + i * 1024;
+    // s_nop 4: the base may have reached its SGPRs through a VALU instruction (v_readfirstlane, v_readlane of a
+    // spilled scalar) right in front of this statement, and a vector-memory instruction must not read such
+    // an SGPR for five wait states; the compiler pads that for its own instructions only.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off[i]), "s"(base), "s"(dst) : "memory");
   }
 }
 
+// Fragment reads of the large-tile kernel work on LDS byte addresses held in registers: one set per
+// operand, computed once, valid for LDS buffer 0 and flipped to the other buffer (bit 16) after every
+// k-step, so that a phase's reads are nothing but ds_read instructions with immediate offsets.
+//   k-contiguous image: addr[kk] (kk = 0, 1) is this lane's 16 bytes of 16-row tile 0; tile t lies
+//     t * 2048 bytes further (the swizzle only involves the row inside the tile).
+//   transposed image: addr[t] is this lane's first 8 bytes of tile t for kk = 0 (the swizzle XORs the
+//     tile index into the chunk, so tiles are not a constant apart); the second k-block of four lies
+//     1024 bytes, kk = 1 lies 8192 bytes further.
 template <bool KMAJOR>
-__device__ __forceinline__ bf16x8 read_frag2(const char* lds, int tile_row0, int kk, int lane) {
-  if (KMAJOR) {
-    return *reinterpret_cast<const bf16x8*>(lds + kmajor2_off(tile_row0 + (lane & 15), 4 * kk + (lane >> 4)));
+struct FragAddr {
+  unsigned addr[KMAJOR ? 2 : 4];
+};
+template <bool KMAJOR>
+__device__ __forceinline__ void frag_addr_init(FragAddr<KMAJOR>& fa, unsigned lds_base, int wave_row0, int lane) {
+  if constexpr (KMAJOR) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fa.addr[kk] = lds_base + kmajor2_off(wave_row0 + (lane & 15), 4 * kk + (lane >> 4));
   } else {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const int k1 = 32 * kk + 8 * g + q;
-    const int c = (tile_row0 >> 3) + (pp >> 1);
-    const int sub = (pp & 1) << 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa.addr[t] = lds_base + rmajor2_off(8 * g + q, ((wave_row0 + 16 * t) >> 3) + (pp >> 1)) + ((pp & 1) << 3);
+  }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void frag_addr_flip(FragAddr<KMAJOR>& fa) {
+#pragma unroll
+  for (int t = 0; t < (KMAJOR ? 2 : 4); ++t) {
+    fa.addr[t] ^= 2 * kTileBytes2;
+    asm volatile("" : "+v"(fa.addr[t]));  // keep the flipped address in its register instead of re-deriving it in front of the reads
+  }
+}
+// Fragment of 16-row tile t, k-substep kk, out of the half-tile image at byte offset HALF_OFF of the buffer.
+template <bool KMAJOR, int HALF_OFF>
+__device__ __forceinline__ bf16x8 read_frag2(const FragAddr<KMAJOR>& fa, int t, int kk) {
+  if constexpr (KMAJOR) {
+    using lds_ptr = const __attribute__((address_space(3))) bf16x8*;
+    return *(lds_ptr)(fa.addr[kk] + HALF_OFF + t * 2048);
+  } else {
     using lds_ptr = __attribute__((address_space(3))) s16x4*;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + rmajor2_off(k1, c) + sub));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + rmajor2_off(k1 + 4, c) + sub));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(fa.addr[t] + HALF_OFF + kk * 8192));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(fa.addr[t] + HALF_OFF + kk * 8192 + 1024));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   }
 }
 
+// LDS map of the large-tile kernel: two k-steps of operands, the GELU table, a 2 KiB epilogue staging
+// strip per wave, and one control word (the id of the next dynamically assigned tile).
+constexpr int kRingBytes = 4 * kTileBytes2;                 // 128 KiB
+constexpr int kStageOff = kRingBytes + kGeluTableBytes;     // 16 rows x 128 B per wave
+constexpr int kCtrlOff = kStageOff + 8 * 2048;
+constexpr int kLdsBytes2 = kCtrlOff + 64;                   // 162,880 of the CU's 163,840 bytes
+constexpr int kNoTile = 0x7fffffff;
+using lds_u32_ptr = volatile __attribute__((address_space(3))) unsigned*;
+constexpr int kStreamingMaxKSteps = 64;  // beyond K = 4096 a tile is long enough to hide its own start
+
 // SPLIT: blockIdx.y selects a contraction range of `k_iters` steps; raw fp32 partial tiles go to
 // p.workspace[blockIdx.y][M][N] (16-byte stores) and splitk_reduce_kernel finishes the product.
+//
+// tile_counter == nullptr: one tile per workgroup (grid = number of tiles, XCD-aware order).
+// tile_counter != nullptr: the grid is at most one workgroup per CU and every workgroup walks a
+// sequence of tiles -- blockIdx.x, blockIdx.x + gridDim.x, then ids drawn from the counter (which the
+// launcher zeroes) -- as ONE stream of k-steps: the half-tile requests run on into the next tile while
+// the current one is finished, so that only the first tile of a workgroup pays the memory latency of a
+// cold start and the next tile's operands are in LDS when the epilogue ends.  Drawing ids instead of
+// fixing them per workgroup keeps the kernel balanced when another stream (a collective) holds some CUs.
 template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT>
-__global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters) {
-  extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 k-steps][B0 | A0 | B1 | A1][GELU' table]
+__global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters, unsigned* tile_counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 k-steps][B0 | A0 | B1 | A1][GELU table][staging][control]
   DPA_STAMP(0);
+  DPA_STAMP_REAL(4);
 
-  float* gelu_tab = reinterpret_cast<float*>(smem2 + 4 * kTileBytes2);
+  float* gelu_tab = reinterpret_cast<float*>(smem2 + kRingBytes);
   if (!SPLIT && (p.aux_mode == kActGelu || p.act == kActGelu)) {
     // backward epilogue: GELU'(x); forward epilogue: Phi(x), so that GELU(x) = x * table[x]
     const bool derivative = p.aux_mode == kActGelu;
@@ -372,94 +429,99 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     __syncthreads();
   }
 
-  const int nwg = tiles_m * tiles_n;
-  const int orig = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  // Each XCD gets a contiguous run of tile ids, and ids are laid out in groups of 8 row-tiles x all
-  // column-tiles, row-tile fastest: the ~32 tiles an XCD works on concurrently then form an 8 x 4
-  // block that touches 12 operand panels per k-step in that XCD's L2 instead of the 33 of a single
-  // column of tiles (+9 % on 8192^3).
-  const int gsz = 8 * tiles_n;
-  const int gid = wgid / gsz, first_m = gid * 8;
-  const int gm = tiles_m - first_m < 8 ? tiles_m - first_m : 8;
-  const int tm = first_m + (wgid % gsz) % gm, tn = (wgid % gsz) / gm;
-  const long long m0 = static_cast<long long>(tm) * BM2, n0 = static_cast<long long>(tn) * BN2;
+  const bool dynamic = !SPLIT && tile_counter != nullptr;
+  const int ntiles = tiles_m * tiles_n;
+  // Tile id -> origin.  Ids are laid out in groups of 8 row-tiles x all column-tiles, row-tile fastest: the
+  // tiles being worked on at any time then form blocks that share operand panels in L2 (an 8 x 4 block
+  // touches 12 panels per k-step instead of the 33 of a single column of tiles, +9 % on 8192^3).  With one
+  // tile per workgroup each XCD (workgroups b, b+8, ...) additionally gets a contiguous run of ids.
+  auto tile_origin = [&](int id, long long& m0, long long& n0) __attribute__((always_inline)) {
+    if (!dynamic) {
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7;
+      id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int gsz = 8 * tiles_n;
+    const int gid = id / gsz, first_m = gid * 8;
+    const int gm = tiles_m - first_m < 8 ? tiles_m - first_m : 8;
+    m0 = static_cast<long long>(first_m + (id % gsz) % gm) * BM2;
+    n0 = static_cast<long long>((id % gsz) / gm) * BN2;
+  };
 
   const u16* A = static_cast<const u16*>(p.A);
   const u16* B = static_cast<const u16*>(p.B);
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = (wid >> 2) * 128, wn = (wid & 3) * 64;
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wr = wid >> 2, wc = wid & 3;
+  const int wm = wr * 128, wn = wc * 64;
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)smem2));
 
   const long long nk_all = p.K / BK2;
   const long long kt0 = SPLIT ? static_cast<long long>(blockIdx.y) * k_iters : 0;
   const long long nk_end = SPLIT ? (kt0 + k_iters < nk_all ? kt0 + k_iters : nk_all) : nk_all;
-  const int n = static_cast<int>(nk_end - kt0);  // k-steps of this workgroup
-  const int wr = wid >> 2, wc = wid & 3;
+  const int n = static_cast<int>(nk_end - kt0);  // k-steps per tile
 
+  // ---- request cursor: where the stream of half-tile requests stands (tile, k-step, LDS buffer).
+  // It enters the next tile at a fixed point of the program -- between phases 1 and 2 of a tile's
+  // second-to-last k-step -- so the steady-state k-steps carry no bookkeeping at all.
+  const long long a_step = A_KMAJOR ? BK2 * 2 : BK2 * 2 * p.lda, b_step = B_KMAJOR ? BK2 * 2 : BK2 * 2 * p.ldb;  // bytes per k-step
   unsigned off_a[2][2], off_b[2][2];
-  dma_offsets<A_KMAJOR, 64>(p.lda, m0, p.M, wid, lane, off_a);
-  dma_offsets<B_KMAJOR, 32>(p.ldb, n0, p.N, wid, lane, off_b);
-  // Request half-tile `which` (kHalfB0 .. kHalfA1) of this workgroup's k-step t into LDS buffer buf.
-  auto request = [&](int which, int t, int buf) __attribute__((always_inline)) {
-    char* dst = smem2 + buf * 2 * kTileBytes2 + which * kHalfBytes;
-    if (which & 1) dma_issue(dma_base<A_KMAJOR>(A, p.lda, m0, (kt0 + t) * BK2), off_a[which >> 1], dst, wid);
-    else dma_issue(dma_base<B_KMAJOR>(B, p.ldb, n0, (kt0 + t) * BK2), off_b[which >> 1], dst, wid);
+  const char *r_aptr = nullptr, *r_bptr = nullptr;
+  unsigned r_dst = lds_base + wid * 2048;  // this wave's first piece of half-tile 0 in the buffer being filled
+  bool r_valid = true;
+  int cur = blockIdx.x;                                                     // tile being multiplied
+  int nxt = dynamic ? static_cast<int>(blockIdx.x + gridDim.x) : kNoTile;   // tile after it
+  auto set_cursor = [&](int id) __attribute__((always_inline)) {
+    long long rm0, rn0;
+    tile_origin(id, rm0, rn0);
+    dma_offsets<A_KMAJOR, 64>(p.lda, rm0, p.M, wid, lane, off_a);
+    dma_offsets<B_KMAJOR, 32>(p.ldb, rn0, p.N, wid, lane, off_b);
+    r_aptr = uniform_ptr(dma_base<A_KMAJOR>(A, p.lda, rm0, kt0 * BK2));
+    r_bptr = uniform_ptr(dma_base<B_KMAJOR>(B, p.ldb, rn0, kt0 * BK2));
   };
+  // Requests the next half-tile of the stream; `which` runs B0 A0 B1 A1 B0 ... by construction of the callers.
+  auto request = [&](auto which_c) __attribute__((always_inline)) {
+    constexpr int which = decltype(which_c)::value;
+    if (which & 1) dma_issue(r_aptr, off_a[which >> 1], r_dst + which * kHalfBytes);
+    else dma_issue(r_bptr, off_b[which >> 1], r_dst + which * kHalfBytes);
+    if (which == kHalfA1) {  // k-step complete
+      r_dst ^= 2 * kTileBytes2;
+      r_aptr += a_step;
+      r_bptr += b_step;
+    }
+  };
+  constexpr std::integral_constant<int, kHalfB0> B0{};
+  constexpr std::integral_constant<int, kHalfA0> A0{};
+  constexpr std::integral_constant<int, kHalfB1> B1{};
+  constexpr std::integral_constant<int, kHalfA1> A1{};
   // nothing may be scheduled across the barrier
   auto phase_barrier = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto lds_reads_done = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
 
-  // Activation-backward epilogue only: the aux tile is fetched by LDS-DMA as well, each wave's 128 x 64
-  // piece in two halves of 64 rows x 128 B (8 KiB, 8 instructions) at  buffer * 64 KiB + wave * 8 KiB.
-  // The first half goes into the buffer that the last k-step leaves idle, so its latency hides behind
-  // that step's MFMAs; the second half follows once the operand buffers are dead.  LDS position
-  // (lane & 7) of row (lane >> 3) receives chunk (lane & 7) ^ (lane >> 3) of the row (XOR on the
-  // source address), which spreads the accumulator-layout reads of the epilogue over the banks.
-  const bool act_bwd = !SPLIT && p.aux_mode != kActNone;
-  const unsigned aux_off = static_cast<unsigned>(((lane >> 3) * p.ldc + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
-  auto aux_request = [&](int half, int stage) __attribute__((always_inline)) {
-    const char* src = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.aux) + (m0 + wm + 64 * half) * p.ldc + n0 + wn));
-    const unsigned dst0 = __builtin_amdgcn_readfirstlane(
-        static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)(smem2 + stage * 2 * kTileBytes2 + wid * 8192))));
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const char* base = uniform_ptr(src + it * 16 * p.ldc);  // 8 rows further
-      const unsigned dst = dst0 + it * 1024;
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(aux_off), "s"(base), "s"(dst) : "memory");
-    }
-  };
-
+  f32x4 acc[8][4];
   // Fragment registers: the A fragments of one 64-row half (reloaded in phase 3), the B fragments of
   // both 32-column halves (kept for the whole k-step: B0 is used again in phase 4).
   bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
-  auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
-    const char* img = smem2 + buf * 2 * kTileBytes2 + (h ? kHalfA1 : kHalfA0) * kHalfBytes;
+  int c_buf = 0;  // LDS buffer holding the k-step being multiplied
+  FragAddr<A_KMAJOR> addr_a;
+  FragAddr<B_KMAJOR> addr_b;
+  frag_addr_init<A_KMAJOR>(addr_a, lds_base, wr * 64, lane);
+  frag_addr_init<B_KMAJOR>(addr_b, lds_base, wc * 32, lane);
+  auto read_a = [&](auto h_c) __attribute__((always_inline)) {
+    constexpr int off = (decltype(h_c)::value ? kHalfA1 : kHalfA0) * kHalfBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag2<A_KMAJOR>(img, wr * 64 + 16 * i, kk, lane);
+      for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag2<A_KMAJOR, off>(addr_a, i, kk);
   };
-  auto read_b = [&](int buf, int h, bf16x8 (&fb)[2][2]) __attribute__((always_inline)) {
-    const char* img = smem2 + buf * 2 * kTileBytes2 + (h ? kHalfB1 : kHalfB0) * kHalfBytes;
+  auto read_b = [&](auto h_c, bf16x8 (&fb)[2][2]) __attribute__((always_inline)) {
+    constexpr int off = (decltype(h_c)::value ? kHalfB1 : kHalfB0) * kHalfBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[kk][j] = read_frag2<B_KMAJOR>(img, wc * 32 + 16 * j, kk, lane);
+      for (int j = 0; j < 2; ++j) fb[kk][j] = read_frag2<B_KMAJOR, off>(addr_b, j, kk);
   };
   // 16 MFMAs: quadrant (row half ah, column half bh) of the wave's tile over the whole k-step
   auto multiply = [&](int ah, int bh, const bf16x8 (&fb)[2][2]) __attribute__((always_inline)) {
@@ -474,168 +536,179 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // One k-step = four phases.  Request order and the reads' phases make every restage safe without
-  // extra waits (t = k-step being multiplied out of buffer buf; "retired" = the reads' data is in
-  // registers on every wave, which the barriers between guarantee):
-  //   phase 1  reads B0 (retired before the phase's first barrier: lgkmcnt(8)) and A0   requests A1 of t+1 -> other buffer
-  //   phase 2  reads B1                                                                 requests B0 of t+2 -> this buffer
-  //   phase 3  reads A1                                                                 requests A0 of t+2
-  //   phase 4  (B0 still in registers)                                                  requests B1 of t+2, waits vmcnt(6)
+  // Activation-backward epilogue only (one tile per workgroup): the aux tile is fetched by LDS-DMA as well,
+  // each wave's 128 x 64 piece in two halves of 64 rows x 128 B (8 KiB, 8 instructions) at
+  // buffer * 64 KiB + wave * 8 KiB.  The first half goes into the buffer that the last k-step leaves idle,
+  // so its latency hides behind that step's MFMAs; the second half follows once the operand buffers are
+  // dead.  LDS position (lane & 7) of row (lane >> 3) receives chunk (lane & 7) ^ (lane >> 3) of the row
+  // (XOR on the source address), which spreads the accumulator-layout reads of the epilogue over the banks.
+  const bool act_bwd = !SPLIT && p.aux_mode != kActNone;
+  const unsigned aux_off = static_cast<unsigned>(((lane >> 3) * p.ldc + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+  long long m0, n0;  // origin of the tile being multiplied
+  auto aux_request = [&](int half, int buf) __attribute__((always_inline)) {
+    const char* src = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.aux) + (m0 + wm + 64 * half) * p.ldc + n0 + wn));
+    const unsigned dst0 = lds_base + buf * 2 * kTileBytes2 + wid * 8192;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const char* base = uniform_ptr(src + it * 16 * p.ldc);  // 8 rows further
+      const unsigned dst = dst0 + it * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(aux_off), "s"(base), "s"(dst) : "memory");
+    }
+  };
+
+  unsigned fetched = 0;  // lane 0 of wave 0: id drawn from the tile counter (lands behind the k-step's vmcnt wait)
+  // The bias values under this lane's accumulators (4 column tiles x 4 columns, packed) are requested in
+  // phase 1 of a tile's last k-step by loads the compiler does not see: its own loads in the epilogue would
+  // be waited for with vmcnt(0), i.e. together with the next tile's half-tiles in flight.  They are older
+  // than the three half-tiles phase 4 leaves in flight, so that phase's wait covers them.
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  u32x2 bias_raw[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+  const unsigned bias_off = static_cast<unsigned>((wn + 4 * (lane >> 4)) * 2);
+  auto bias_request = [&]() __attribute__((always_inline)) {
+    const char* base = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.bias) + n0));
+    asm volatile(
+        "s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5\n\tglobal_load_dwordx2 %1, %4, %5 offset:32\n\t"
+        "global_load_dwordx2 %2, %4, %5 offset:64\n\tglobal_load_dwordx2 %3, %4, %5 offset:96"
+        : "=&v"(bias_raw[0]), "=&v"(bias_raw[1]), "=&v"(bias_raw[2]), "=&v"(bias_raw[3])
+        : "v"(bias_off), "s"(base)
+        : "memory");
+  };
+
+  // One k-step = four phases; each phase is {fragment reads + one half-tile request | barrier | 16 MFMAs |
+  // barrier}.  The request order and the reads' phases make every restage safe without further waits
+  // ("retired" = the reads' data is in registers on every wave, which the barriers between guarantee):
+  //   phase 1  reads B0 (retired before the phase's first barrier: lgkmcnt(8)) and A0   requests A1 of the next k-step -> other buffer
+  //   phase 2  reads B1                                                                 requests B0 of the k-step after  -> this buffer
+  //   phase 3  reads A1                                                                 requests A0 of the k-step after
+  //   phase 4  (B0 still in registers)                                                  requests B1 of the k-step after, waits vmcnt(6)
   // A half-tile is requested again at the earliest two phases after its last read (B0: one phase, after
-  // the early wait), and the vmcnt(6) of phase 4 -- everything but the three newest half-tiles has
-  // landed, i.e. all of k-step t+1 -- is followed by two barriers before phase 1 of t+1 reads it.
-  auto k_step = [&](int t, auto buf_c) __attribute__((always_inline)) {
-    constexpr int buf = decltype(buf_c)::value;
-    const bool next1 = t + 1 < n, next2 = t + 2 < n;
+  // the early wait; the reads of a phase are complete when its MFMAs are, i.e. before its second barrier),
+  // and the vmcnt(6) of phase 4 -- everything but the three newest half-tiles has landed, i.e. all of the
+  // next k-step -- is followed by two barriers before phase 1 reads it.
+  // KIND 0: steady state (the cursor is inside this tile: every request is issued).
+  // KIND 1: a tile's second-to-last k-step: draws the id of the tile after next, and moves the cursor
+  //         into the next tile after the request of phase 1.
+  // KIND 2: a tile's last k-step: the cursor is in the next tile, if there is one; requests what the
+  //         epilogue will need (bias, first half of the aux tile).
+  auto k_step = [&](auto kind_c) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
     // phase 1
-    read_b(buf, 0, fb0);
+    read_b(std::integral_constant<int, 0>{}, fb0);
     __builtin_amdgcn_sched_barrier(0);
-    read_a(buf, 0);
+    read_a(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
-    if (next1) request(kHalfA1, t + 1, buf ^ 1);
-    else if (act_bwd) aux_request(0, buf ^ 1);
+    if (KIND == 1 && dynamic && threadIdx.x == 0) {
+      const unsigned one = 1u, zero = 0u;
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zero), "v"(one), "s"(tile_counter) : "memory");
+    }
+    if (KIND == 2 && !SPLIT && p.bias != nullptr && n0 + BN2 <= p.N) bias_request();
+    if (KIND == 2 && act_bwd) aux_request(0, c_buf ^ 1);
+    else if (KIND != 2 || r_valid) request(A1);
+    if (KIND == 1) {
+      if (nxt < ntiles) set_cursor(nxt);
+      else r_valid = false;
+    }
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     phase_barrier();
-    lds_reads_done();
     multiply(0, 0, fb0);
     phase_barrier();
     // phase 2
-    read_b(buf, 1, fb1);
+    read_b(std::integral_constant<int, 1>{}, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    if (next2) request(kHalfB0, t + 2, buf);
+    if (KIND == 0 || r_valid) request(B0);
     phase_barrier();
-    lds_reads_done();
     multiply(0, 1, fb1);
     phase_barrier();
     // phase 3
-    read_a(buf, 1);
+    read_a(std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
-    if (next2) request(kHalfA0, t + 2, buf);
+    if (KIND == 0 || r_valid) request(A0);
     phase_barrier();
-    lds_reads_done();
     multiply(1, 1, fb1);
     phase_barrier();
     // phase 4
-    if (next2) {
-      request(kHalfB1, t + 2, buf);
+    if (KIND == 0 || r_valid) {
+      request(B1);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (next1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!(KIND == 2 && act_bwd)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // end of the stream: whatever is still in flight
     }
+    c_buf ^= 1;
+    frag_addr_flip<A_KMAJOR>(addr_a);
+    frag_addr_flip<B_KMAJOR>(addr_b);
     phase_barrier();
     multiply(1, 0, fb0);
     phase_barrier();
   };
 
-  // prologue: all of k-step 0 and three half-tiles of k-step 1
-  request(kHalfB0, 0, 0);
-  request(kHalfA0, 0, 0);
-  request(kHalfB1, 0, 0);
-  request(kHalfA1, 0, 0);
+  // prologue: all of the first k-step and three half-tiles of the second
+  set_cursor(cur);
+  request(B0);
+  request(A0);
+  request(B1);
+  request(A1);
   if (n > 1) {
-    request(kHalfB0, 1, 1);
-    request(kHalfA0, 1, 1);
-    request(kHalfB1, 1, 1);
+    request(B0);
+    request(A0);
+    request(B1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
+    r_valid = false;  // one k-step per tile: one tile per workgroup (the launcher's choice)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   phase_barrier();
   DPA_STAMP(1);
-  if (wr == 1) phase_barrier();  // the upper wave row runs one barrier behind
-  for (int t = 0; t < n; t += 2) {
-    k_step(t, std::integral_constant<int, 0>{});
-    if (t + 1 < n) k_step(t + 1, std::integral_constant<int, 1>{});
-  }
-  if (wr == 0) phase_barrier();
-  DPA_STAMP(2);
-  if (SPLIT) {
-    float* ws = p.workspace + static_cast<long long>(blockIdx.y) * p.M * p.N;
+
+  while (true) {
+    tile_origin(cur, m0, n0);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const long long row = m0 + wm + 16 * i + (lane & 15), col0 = n0 + wn + 16 * j + 4 * (lane >> 4);
-        if (row < p.M && col0 < p.N) *reinterpret_cast<f32x4*>(ws + row * p.N + col0) = acc[i][j];  // N % 4 == 0 on this path
-      }
-    return;
-  }
-  // Epilogue.  Straight from the accumulators a wave-wide store covers 16 rows x 32 bytes, which the
-  // memory system handles at about a third of its streaming rate (the epilogue alone used to take as
-  // long as ten k-steps).  Full interior tiles therefore go through LDS, which is free once the
-  // last k-step is done: each wave transposes its 128 x 64 sub-tile in two halves of 64 rows
-  // (144-byte row pitch: conflict-free 8-byte writes and 16-byte reads) and writes 8 rows x 128
-  // contiguous bytes per store instruction.  Bias and activation are applied in registers first.
-  // (A persistent one-workgroup-per-CU variant that requests the next tile's first k-step before the
-  // epilogue was measured 10-20 % slower: its top-of-loop vmcnt(0) also waits for the output stores
-  // to drain, which the hardware overlaps for free when a fresh workgroup takes over the CU; a second
-  // attempt that requested the next tile after the last k-step, kept the epilogue inside the last stage
-  // and waited for the request before the first store was 4-7 % faster than one workgroup per tile in
-  // the same code, but the tile loop around the main loop cost registers the main loop does not have
-  // (64-106 spilled VGPRs, some inside the k-loop of the NN / TN variants) and the sum was 20 % slower.  A
-  // 128x256x32 tile with two independent 4-wave workgroups per CU, meant to cover one workgroup's
-  // prologue / epilogue with the other's main loop, was 7-20 % slower as well: half the MFMAs per
-  // barrier and 1.5x the global->LDS traffic per flop cost more than the overlap returns.)
-  const bool staged = p.beta == 0.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_act)) & 15) == 0;
-  if (staged) {
-    constexpr int kPitch = 144;
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();  // every wave has finished reading the operand stages
-    __builtin_amdgcn_sched_barrier(0);
-    char* mine = smem2 + wid * (64 * kPitch);
-    const u16* bias = static_cast<const u16*>(p.bias);
-    float bv[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
-      if (bias) {
-        const u16x4 b4 = *reinterpret_cast<const u16x4*>(bias + n0 + wn + 16 * j + 4 * (lane >> 4));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[j][e] = BF16::to_f32(b4[e]);
-      }
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // The upper wave row runs one barrier behind the lower one inside the k-steps: on every SIMD one
+    // wave multiplies while its partner reads LDS and issues requests.
+    if (wr == 1) phase_barrier();
+#pragma unroll 1
+    for (int t = 0; t < n - 2; ++t) k_step(std::integral_constant<int, 0>{});
+    if (n > 1) k_step(std::integral_constant<int, 1>{});
+    k_step(std::integral_constant<int, 2>{});
+    if (dynamic && wid == 0) {
+      // the counter's answer is in (it is older than the requests a vmcnt(6) leaves in flight)
+      asm volatile("" : "+v"(fetched));
+      *(lds_u32_ptr)(smem2 + kCtrlOff) = __builtin_amdgcn_readfirstlane(fetched);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave reaches the barrier below
     }
-    // one pass per output tensor: the pre-activation (when the backward will need it), then the result.
-    // The activation is a compile-time parameter: selected per element it costs a scalar branch for each
-    // of the 128 values a lane owns, more than the arithmetic.
-    auto emit = [&](u16* out, int half, auto act_c) __attribute__((always_inline)) {
-      constexpr int ACT = decltype(act_c)::value;
+    if (wr == 0) phase_barrier();
+    DPA_STAMP(2);
+
+    if (SPLIT) {
+      float* ws = p.workspace + static_cast<long long>(blockIdx.y) * p.M * p.N;
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4& a = acc[4 * half + ii][j];
-          u16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = BF16::from_f32(p.alpha * a[e] + bv[j][e]);
-            // the activation sees the pre-activation rounded to bf16, exactly as the unfused path stores and re-reads it
-            if (ACT == kActGelu) {
-              const int bits = o[e];
-              int idx = (bits & 0x7fff) - kGeluLo;
-              idx = idx < 0 ? 0 : (idx > kGeluEntries - 1 ? kGeluEntries - 1 : idx);
-              o[e] = BF16::from_f32(BF16::to_f32(o[e]) * gelu_tab[idx + (bits >> 15) * kGeluEntries]);
-            } else if (ACT != kActNone) {
-              o[e] = BF16::from_f32(act_fn(BF16::to_f32(o[e]), ACT));
-            }
-          }
-          *reinterpret_cast<u16x4*>(mine + (16 * ii + (lane & 15)) * kPitch + (16 * j + 4 * (lane >> 4)) * 2) = o;
+          const long long row = m0 + wm + 16 * i + (lane & 15), col0 = n0 + wn + 16 * j + 4 * (lane >> 4);
+          if (row < p.M && col0 < p.N) *reinterpret_cast<f32x4*>(ws + row * p.N + col0) = acc[i][j];  // N % 4 == 0 on this path
         }
-      // the wave reads back only what it wrote itself, and the LDS serves one wave's requests in order
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int rl = 8 * it + (lane >> 3), ch = lane & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(mine + rl * kPitch + ch * 16);
-        *reinterpret_cast<u32x4*>(out + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8) = v;
-      }
-    };
-    if (act_bwd) {
+      return;
+    }
+    // Epilogue.  Straight from the accumulators a wave-wide store covers 16 rows x 32 bytes, which the
+    // memory system handles at about a third of its streaming rate.  Full interior tiles therefore go
+    // through LDS: each wave transposes its 128 x 64 sub-tile 16 rows at a time in a 2 KiB strip of its
+    // own (128-byte rows, 16-byte chunks XOR-swizzled by the row: conflict-free 8-byte writes and 16-byte
+    // reads) and writes 8 rows x 128 contiguous bytes per store instruction.  Bias and activation are
+    // applied in registers first.  The strips lie outside the operand buffers, which already receive the
+    // next tile.
+    const bool staged = p.beta == 0.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_act)) & 15) == 0;
+    if (staged && act_bwd) {
       // Activation-backward epilogue: C = (alpha*acc) * act'(aux).  Each lane picks the aux values
       // that sit under its accumulators out of the DMA image, writes the result back into the same
       // cells, and the rows then leave as 8 rows x 128 contiguous bytes per store instruction -- so
       // neither direction touches global memory with the accumulator layout's 32-byte row pieces.
-      const int last = (n - 1) & 1;  // stage of the last k-step; half 0 sits in the other one
+      phase_barrier();                     // every wave has finished reading the operand buffers
+      const int last = (n - 1) & 1;        // buffer of the last k-step; half 0 sits in the other one
       aux_request(1, last);
       u16* Cout = static_cast<u16*>(p.C);
       float csum = 0.f;  // lane c: column n0 + wn + c of this wave's 128 rows
@@ -693,24 +766,88 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       if (p.colsum_partial) p.colsum_partial[(2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + lane] = csum;
       return;
     }
-    auto emit_all = [&](auto act_c) __attribute__((always_inline)) {
+    if (staged) {
+      using lds_u16x4_ptr = __attribute__((address_space(3))) u16x4*;
+      using lds_u32x4_ptr = const __attribute__((address_space(3))) u32x4*;
+      const int r = lane & 15, g = lane >> 4;
+      const unsigned mine = lds_base + kStageOff + wid * 2048;
+      const unsigned wr_addr = mine + r * 128 + 8 * (g & 1);       // + ((chunk ^ (r & 7)) << 4) per column tile
+      const unsigned rd_addr = mine + (lane >> 3) * 128 + (lane & 7) * 16;
+      const int out_col = ((lane & 7) ^ (lane >> 3)) * 8;
+      if (p.bias == nullptr) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (p.pre_act) emit(static_cast<u16*>(p.pre_act), half, std::integral_constant<int, kActNone>{});
-        emit(static_cast<u16*>(p.C), half, act_c);
+        for (int j = 0; j < 4; ++j) bias_raw[j] = u32x2{0u, 0u};
       }
-    };
-    if (p.act == kActGelu) emit_all(std::integral_constant<int, kActGelu>{});
-    else if (p.act == kActRelu) emit_all(std::integral_constant<int, kActRelu>{});
-    else emit_all(std::integral_constant<int, kActNone>{});
+      // one pass per output tensor and 16 rows: the pre-activation (when the backward will need it), then
+      // the result.  The activation is a compile-time parameter: selected per element it costs a scalar
+      // branch for each of the 128 values a lane owns, more than the arithmetic.
+      auto emit = [&](u16* out_rows, int i, auto act_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4& a = acc[i][j];
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bias_e = __uint_as_float(e & 1 ? bias_raw[j][e >> 1] & 0xffff0000u : bias_raw[j][e >> 1] << 16);
+            o[e] = BF16::from_f32(p.alpha * a[e] + bias_e);
+            // the activation sees the pre-activation rounded to bf16, exactly as the unfused path stores and re-reads it
+            if (ACT == kActGelu) {
+              const int bits = o[e];
+              int idx = (bits & 0x7fff) - kGeluLo;
+              idx = idx < 0 ? 0 : (idx > kGeluEntries - 1 ? kGeluEntries - 1 : idx);
+              o[e] = BF16::from_f32(BF16::to_f32(o[e]) * gelu_tab[idx + (bits >> 15) * kGeluEntries]);
+            } else if (ACT != kActNone) {
+              o[e] = BF16::from_f32(act_fn(BF16::to_f32(o[e]), ACT));
+            }
+          }
+          *(lds_u16x4_ptr)(wr_addr + (((2 * j + (g >> 1)) ^ (r & 7)) << 4)) = o;
+        }
+        // the wave reads back only what it wrote itself, and the LDS serves one wave's requests in order
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const u32x4 v = *(lds_u32x4_ptr)(rd_addr + it * 1024);
+          *reinterpret_cast<u32x4*>(out_rows + static_cast<long long>(8 * it) * p.ldc) = v;
+        }
+      };
+      auto emit_all = [&](auto act_c) __attribute__((always_inline)) {
+        // this lane's element of the tile's first 8 rows; advanced 16 rows per pass (the pin keeps the
+        // compiler from holding all sixteen row pointers in registers at once)
+        const long long first = (m0 + wm + (lane >> 3)) * p.ldc + n0 + wn + out_col;
+        u16* c_rows = static_cast<u16*>(p.C) + first;
+        u16* p_rows = p.pre_act ? static_cast<u16*>(p.pre_act) + first : nullptr;
+        const long long pass_step = 16 * p.ldc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (p_rows) emit(p_rows, i, std::integral_constant<int, kActNone>{});
+          emit(c_rows, i, act_c);
+          c_rows += pass_step;
+          asm volatile("" : "+v"(c_rows));
+          if (p_rows) {
+            p_rows += pass_step;
+            asm volatile("" : "+v"(p_rows));
+          }
+        }
+      };
+      if (p.act == kActGelu) emit_all(std::integral_constant<int, kActGelu>{});
+      else if (p.act == kActRelu) emit_all(std::integral_constant<int, kActRelu>{});
+      else emit_all(std::integral_constant<int, kActNone>{});
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          store_tile_bf16(p, acc[i][j], m0 + wm + 16 * i + (lane & 15), n0 + wn + 16 * j + 4 * (lane >> 4));
+    }
     DPA_STAMP(3);
-    return;
+    DPA_STAMP_REAL(5);
+    if (!dynamic) return;
+    // next tile: the id drawn while this one was multiplied becomes the one after it
+    cur = nxt;
+    if (cur >= ntiles) return;
+    const unsigned drawn = __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
+    nxt = static_cast<int>(2u * gridDim.x + drawn);
   }
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      store_tile_bf16(p, acc[i][j], m0 + wm + 16 * i + (lane & 15), n0 + wn + 16 * j + 4 * (lane >> 4));
 }
 
 // Sums the split-K partials in index order (deterministic) and applies the regular epilogue.
@@ -792,6 +929,37 @@ bool gemm_bf16_supported(const GemmArgs& a) {
   return tiles < (1ll << 31);
 }
 
+// Tile counters of the streaming (several tiles per workgroup) launches: a small ring of 16-byte slots
+// in the code object's own memory, one per launch in flight, zeroed on the launch's stream.
+__device__ unsigned g_tile_counters[256 * 4];
+
+struct StreamingSetup {
+  unsigned* counters = nullptr;
+  int cus = 0;
+  unsigned next_slot = 0;
+};
+StreamingSetup& streaming_setup() {
+  static StreamingSetup s = [] {
+    StreamingSetup t;
+    void* addr = nullptr;
+    if (hipGetSymbolAddress(&addr, HIP_SYMBOL(g_tile_counters)) == hipSuccess) t.counters = static_cast<unsigned*>(addr);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) t.cus = prop.multiProcessorCount;
+    return t;
+  }();
+  return s;
+}
+
+// Several tiles per workgroup pay off when a tile is short (few k-steps): the cold start and the
+// drain of a workgroup are then a visible share of its time.
+bool use_streaming(const GemmArgs& a, long long tiles, bool split) {
+  if (split || a.aux_mode != kActNone) return false;
+  const long long nk = a.K / BK2;
+  const StreamingSetup& s = streaming_setup();
+  return s.counters != nullptr && s.cus > 0 && nk >= 2 && nk <= kStreamingMaxKSteps && tiles >= 3ll * s.cus;
+}
+
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   const bool split = a.split_k > 1 && a.workspace != nullptr;
   // the activation-backward epilogue exists in the large-tile kernel only (callers check
@@ -800,25 +968,34 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
     const int tm2 = static_cast<int>((a.M + BM2 - 1) / BM2), tn2 = static_cast<int>((a.N + BN2 - 1) / BN2);
     const long long nk = a.K / BK2;
     const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);
-    const dim3 grid2(static_cast<unsigned>(tm2) * static_cast<unsigned>(tn2), split ? static_cast<unsigned>(a.split_k) : 1u);
-    // 128 KiB (+ the GELU' table): above the 64 KiB default, so the limit is raised per kernel
-    const size_t lds2 = 4 * kTileBytes2 + (split ? 0 : kGeluTableBytes);
+    const long long tiles = static_cast<long long>(tm2) * tn2;
+    unsigned* counter = nullptr;
+    unsigned grid_x = static_cast<unsigned>(tiles);
+    if (use_streaming(a, tiles, split)) {
+      StreamingSetup& s = streaming_setup();
+      counter = s.counters + 4 * (s.next_slot++ & 255u);
+      (void)hipMemsetAsync(counter, 0, 16, stream);
+      grid_x = static_cast<unsigned>(s.cus);
+    }
+    const dim3 grid2(grid_x, split ? static_cast<unsigned>(a.split_k) : 1u);
+    // all of a CU's LDS but 960 bytes: above the 64 KiB default, so the limit is raised per kernel
+    const size_t lds2 = kLdsBytes2;
     auto go2 = [&](auto ak, auto bk) {
       constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
       static bool configured = false;
       if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes2 + kGeluTableBytes);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTileBytes2 + kGeluTableBytes);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes2);
         configured = true;
       }
       if (split) {
-        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, true>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, true>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters, counter);
         const long long quads = a.M * (a.N >> 2);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, stream, a);
       } else {
-        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, false>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters);
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, false>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters, counter);
       }
     };
     if (a.a_kmajor && a.b_kmajor) go2(std::true_type{}, std::true_type{});

@@ -59,24 +59,29 @@ struct Problem {
 };
 
 // launches the 256x256 kernel whatever the shape (the dispatcher would send small products to the 128x128 kernel)
-static void launch_large(const GemmArgs& a, hipStream_t st) {
+static void launch_large(const GemmArgs& a, hipStream_t st, bool streaming = false) {
   using namespace dpa::kernels;
+  static unsigned* counter = nullptr;
+  if (!counter) CK(hipMalloc(&counter, 16));
   const bool split = a.split_k > 1 && a.workspace;
   const int tm = static_cast<int>((a.M + 255) / 256), tn = static_cast<int>((a.N + 255) / 256);
   const long long nk = a.K / 64;
   const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);
-  const dim3 grid(tm * tn, split ? a.split_k : 1);
-  const size_t lds = 4 * kTileBytes2 + kGeluTableBytes;
+  streaming = streaming && !split && nk >= 2;
+  if (streaming) CK(hipMemsetAsync(counter, 0, 16, st));
+  unsigned* ctr = streaming ? counter : nullptr;
+  const dim3 grid(streaming ? std::min(tm * tn, 256) : tm * tn, split ? a.split_k : 1);
+  const size_t lds = kLdsBytes2;
   auto go = [&](auto ak, auto bk) {
     constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (split) {
-      hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, true>), grid, dim3(512), lds, st, a, tm, tn, k_iters);
+      hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, true>), grid, dim3(512), lds, st, a, tm, tn, k_iters, ctr);
       const long long quads = a.M * (a.N >> 2);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, st, a);
     } else {
-      hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, false>), grid, dim3(512), lds, st, a, tm, tn, k_iters);
+      hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, false>), grid, dim3(512), lds, st, a, tm, tn, k_iters, ctr);
     }
   };
   if (a.a_kmajor && a.b_kmajor) go(std::true_type{}, std::true_type{});
@@ -85,14 +90,14 @@ static void launch_large(const GemmArgs& a, hipStream_t st) {
   else go(std::false_type{}, std::false_type{});
 }
 
-static int check_one(long long M, long long N, long long K, int ak, int bk, int split, int reps) {
+static int check_one(long long M, long long N, long long K, int ak, int bk, int split, int reps, bool streaming = false) {
   Problem p(M, N, K, ak, bk, 1234 + static_cast<unsigned>(M * 7 + N * 3 + K + ak * 2 + bk));
   p.split(split);
   std::vector<unsigned short> out0(M * N), out(M * N);
   int bad = 0, nondet = 0;
   for (int r = 0; r < reps; ++r) {
     CK(hipMemset(p.C, 0xff, M * N * 2));
-    launch_large(p.args, 0);
+    launch_large(p.args, 0, streaming);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(out.data(), p.C, M * N * 2, hipMemcpyDeviceToHost));
     if (r == 0) out0 = out;
@@ -114,7 +119,7 @@ static int check_one(long long M, long long N, long long K, int ak, int bk, int 
     if (!(err <= tol)) { if (bad < 5) printf("    mismatch (%lld,%lld): got %.4f ref %.4f\n", m, n, got, ref); ++bad; }
     worst = std::max(worst, err / (std::fabs(ref) + 1.0));
   }
-  printf("%s%s M=%lld N=%lld K=%lld split=%d : %s  (bad %d / %lld, worst rel %.3g, nondeterministic runs %d / %d)\n", ak ? "N" : "T", bk ? "T" : "N",
+  printf("%s%s%s M=%lld N=%lld K=%lld split=%d : %s  (bad %d / %lld, worst rel %.3g, nondeterministic runs %d / %d)\n", streaming ? "streaming " : "", ak ? "N" : "T", bk ? "T" : "N",
          M, N, K, split, (bad || nondet) ? "FAIL" : "ok", bad, samples, worst, nondet, reps - 1);
   fflush(stdout);
   return (bad || nondet) ? 1 : 0;
@@ -146,6 +151,10 @@ int main(int argc, char** argv) {
                         {4096, 2304, 768, 1}, {8192, 768, 3072, 1}, {2048, 2048, 8192, 1}};
     for (const auto& l : layouts)
       for (const auto& s : shapes) fails += check_one(s.M, s.N, s.K, l[0], l[1], s.split, 4);
+    // several tiles per workgroup (ids drawn from the counter): more tiles than CUs, 2 .. 48 k-steps, ragged edges
+    const S stream_shapes[] = {{8192, 4096, 128, 1}, {16384, 2304, 192, 1}, {12288, 3072, 768, 1}, {8440, 2312, 256, 1}, {65536, 768, 3072, 1}, {2048, 1024, 512, 1}};
+    for (const auto& l : layouts)
+      for (const auto& s : stream_shapes) fails += check_one(s.M, s.N, s.K, l[0], l[1], 1, 4, true);
     printf(fails ? "FAILED: %d cases\n" : "all cases passed (%d failures)\n", fails);
     return fails ? 1 : 0;
   }
@@ -192,6 +201,16 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 3; ++i) d[i].push_back(static_cast<double>(h[w * 8 + i + 1] - h[w * 8 + i]));
       lo = std::min(lo, h[w * 8]); hi = std::max(hi, h[w * 8 + 3]);
     }
+    std::vector<double> clk; double busy = 0; unsigned long long rlo = ~0ull, rhi = 0;
+    for (long long w = 0; w < nwg; ++w) {
+      const double dc = static_cast<double>(h[w * 8 + 3] - h[w * 8]), dr = static_cast<double>(h[w * 8 + 5] - h[w * 8 + 4]);
+      clk.push_back(dc / dr * 0.1);  // GHz: the real-time counter runs at 100 MHz
+      busy += dr;
+      rlo = std::min(rlo, h[w * 8 + 4]); rhi = std::max(rhi, h[w * 8 + 5]);
+    }
+    std::sort(clk.begin(), clk.end());
+    printf("  in-kernel clock median %.2f GHz; workgroups resident %.1f %% of 256 CUs x (first entry -> last exit = %.1f us)\n", clk[clk.size() / 2],
+           100.0 * busy / 256.0 / static_cast<double>(rhi - rlo), (rhi - rlo) * 0.01);
     for (auto& v : d) std::sort(v.begin(), v.end());
     printf("%s %lldx%lldx%lld: %.1f us wall; first stamp -> last stamp %.0f cycles => clock %.2f GHz\n", L.c_str(), M, N, K, ms * 1e3, static_cast<double>(hi - lo),
            (hi - lo) / (ms * 1e-3) / 1e9);

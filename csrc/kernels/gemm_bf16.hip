@@ -293,6 +293,12 @@ using lptr_t = __attribute__((address_space(3))) void*;
 // row / column owns 2*SPAN consecutive rows of the full tile.
 template <bool KMAJOR, int SPAN>
 __device__ __forceinline__ void dma_offsets(long long ld, long long r0, long long R, int wid, int lane, unsigned (&off)[2][2]) {
+  // 32-bit arithmetic throughout (the cursor moves to a new tile in the middle of a k-step, next to 180
+  // live fragment and accumulator registers): a tile-relative row < 256 times a row pitch < 8 MiB.
+  const unsigned ld2 = static_cast<unsigned>(ld) * 2u;
+  // last valid row (k-contiguous operand) or last valid 8-row chunk start (the dispatcher requires R % 8 == 0), tile-relative
+  const long long room = R - r0 - (KMAJOR ? 1 : 8);
+  const unsigned lim = static_cast<unsigned>(room < 255 ? room : 255);
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -301,16 +307,16 @@ __device__ __forceinline__ void dma_offsets(long long ld, long long r0, long lon
       if (KMAJOR) {
         const int lr = piece * 8 + (lane >> 3);                   // 8 local rows of 128 B per piece
         const int c = (lane & 7) ^ ((lr >> 1) & 7);               // logical chunk that belongs at this physical slot
-        long long gr = r0 + (lr / SPAN) * (2 * SPAN) + h * SPAN + lr % SPAN;
-        gr = gr < R ? gr : R - 1;                                 // rows past the edge re-read the last row
-        off[h][i] = static_cast<unsigned>(((gr - r0) * ld + c * 8) * 2);
+        unsigned rel = static_cast<unsigned>((lr / SPAN) * (2 * SPAN) + h * SPAN + lr % SPAN);
+        rel = rel < lim ? rel : lim;                              // rows past the edge re-read the last row
+        off[h][i] = rel * ld2 + static_cast<unsigned>(c * 16);
       } else {
         const int k = piece * 4 + (lane >> 4);                    // 4 k-rows of 256 B per piece
         const int c = (lane & 15) ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)));
         const int lr = c * 8;                                     // first of the chunk's 8 local rows
-        long long gc = r0 + (lr / SPAN) * (2 * SPAN) + h * SPAN + lr % SPAN;
-        gc = gc + 8 <= R ? gc : (R - 8);                          // R % 8 == 0 is required by the dispatcher
-        off[h][i] = static_cast<unsigned>((k * ld + (gc - r0)) * 2);
+        unsigned rel = static_cast<unsigned>((lr / SPAN) * (2 * SPAN) + h * SPAN + lr % SPAN);
+        rel = rel < lim ? rel : lim;
+        off[h][i] = static_cast<unsigned>(k) * ld2 + rel * 2u;
       }
     }
 }
@@ -391,11 +397,12 @@ __device__ __forceinline__ bf16x8 read_frag2(const FragAddr<KMAJOR>& fa, int t, 
 }
 
 // LDS map of the large-tile kernel: two k-steps of operands, the GELU table, a 2 KiB epilogue staging
-// strip per wave, and one control word (the id of the next dynamically assigned tile).
+// strip per wave, one control word (the id of the next dynamically assigned tile) and a tile's bias values.
 constexpr int kRingBytes = 4 * kTileBytes2;                 // 128 KiB
 constexpr int kStageOff = kRingBytes + kGeluTableBytes;     // 16 rows x 128 B per wave
 constexpr int kCtrlOff = kStageOff + 8 * 2048;
-constexpr int kLdsBytes2 = kCtrlOff + 64;                   // 162,880 of the CU's 163,840 bytes
+constexpr int kBiasOff = kCtrlOff + 64;                     // the next tile's 256 bias values (bf16)
+constexpr int kLdsBytes2 = kBiasOff + 512;                  // 163,392 of the CU's 163,840 bytes
 constexpr int kNoTile = 0x7fffffff;
 using lds_u32_ptr = volatile __attribute__((address_space(3))) unsigned*;
 constexpr int kStreamingMaxKSteps = 64;  // beyond K = 4096 a tile is long enough to hide its own start
@@ -470,11 +477,21 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   bool r_valid = true;
   int cur = blockIdx.x;                                                     // tile being multiplied
   int nxt = dynamic ? static_cast<int>(blockIdx.x + gridDim.x) : kNoTile;   // tile after it
+  // per-lane source offsets of the cursor's tile (recomputed after every epilogue rather than kept across it)
+  auto set_offsets = [&](int id) __attribute__((always_inline)) {
+    long long rm0, rn0;
+    tile_origin(id, rm0, rn0);
+    // an opaque copy of the lane index: the compiler would otherwise hoist the lane-only parts of all eight
+    // offsets to the top of the kernel and keep (spill) them across everything
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    dma_offsets<A_KMAJOR, 64>(p.lda, rm0, p.M, wid, l, off_a);
+    dma_offsets<B_KMAJOR, 32>(p.ldb, rn0, p.N, wid, l, off_b);
+  };
   auto set_cursor = [&](int id) __attribute__((always_inline)) {
     long long rm0, rn0;
     tile_origin(id, rm0, rn0);
-    dma_offsets<A_KMAJOR, 64>(p.lda, rm0, p.M, wid, lane, off_a);
-    dma_offsets<B_KMAJOR, 32>(p.ldb, rn0, p.N, wid, lane, off_b);
+    set_offsets(id);
     r_aptr = uniform_ptr(dma_base<A_KMAJOR>(A, p.lda, rm0, kt0 * BK2));
     r_bptr = uniform_ptr(dma_base<B_KMAJOR>(B, p.ldb, rn0, kt0 * BK2));
   };
@@ -557,21 +574,18 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   };
 
   unsigned fetched = 0;  // lane 0 of wave 0: id drawn from the tile counter (lands behind the k-step's vmcnt wait)
-  // The bias values under this lane's accumulators (4 column tiles x 4 columns, packed) are requested in
-  // phase 1 of a tile's last k-step by loads the compiler does not see: its own loads in the epilogue would
-  // be waited for with vmcnt(0), i.e. together with the next tile's half-tiles in flight.  They are older
-  // than the three half-tiles phase 4 leaves in flight, so that phase's wait covers them.
-  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-  u32x2 bias_raw[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
-  const unsigned bias_off = static_cast<unsigned>((wn + 4 * (lane >> 4)) * 2);
-  auto bias_request = [&]() __attribute__((always_inline)) {
-    const char* base = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.bias) + n0));
-    asm volatile(
-        "s_nop 4\n\tglobal_load_dwordx2 %0, %4, %5\n\tglobal_load_dwordx2 %1, %4, %5 offset:32\n\t"
-        "global_load_dwordx2 %2, %4, %5 offset:64\n\tglobal_load_dwordx2 %3, %4, %5 offset:96"
-        : "=&v"(bias_raw[0]), "=&v"(bias_raw[1]), "=&v"(bias_raw[2]), "=&v"(bias_raw[3])
-        : "v"(bias_off), "s"(base)
-        : "memory");
+  // The bias is added by starting a tile's accumulators at the bias values of their columns instead of at
+  // zero, so the epilogue is a plain conversion.  A tile's 256 values are fetched one tile ahead -- in front
+  // of the prologue for a workgroup's first tile, in phase 1 of the previous tile's last k-step otherwise --
+  // by wave 0 with two LDS-DMA instructions; they are older than the half-tiles the next counted wait leaves
+  // in flight, so that wait (and the barrier behind it) publishes them like an operand tile.
+  auto bias_request = [&](long long bn0) __attribute__((always_inline)) {
+    if (wid != 0) return;
+    const char* base = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.bias) + bn0));
+    const unsigned voff = static_cast<unsigned>(lane * 4);
+    const unsigned dst = lds_base + kBiasOff;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(base + 256), "s"(dst + 256) : "memory");
   };
 
   // One k-step = four phases; each phase is {fragment reads + one half-tile request | barrier | 16 MFMAs |
@@ -585,26 +599,36 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   // the early wait; the reads of a phase are complete when its MFMAs are, i.e. before its second barrier),
   // and the vmcnt(6) of phase 4 -- everything but the three newest half-tiles has landed, i.e. all of the
   // next k-step -- is followed by two barriers before phase 1 reads it.
-  // KIND 0: steady state (the cursor is inside this tile: every request is issued).
-  // KIND 1: a tile's second-to-last k-step: draws the id of the tile after next, and moves the cursor
+  // FIRST:  a tile's first k-step.  When the tile follows another one of this workgroup, A1 of the second
+  //         k-step was already requested in front of that tile's epilogue (a1_ahead), and the stores of
+  //         that epilogue (ahead_stores of them) are younger than it: the wait of phase 4 then leaves
+  //         them in flight as well instead of waiting for the output to reach memory.
+  // PENULT: a tile's second-to-last k-step: draws the id of the tile after next, and moves the cursor
   //         into the next tile after the request of phase 1.
-  // KIND 2: a tile's last k-step: the cursor is in the next tile, if there is one; requests what the
+  // LAST:   a tile's last k-step: the cursor is in the next tile, if there is one; requests what the
   //         epilogue will need (bias, first half of the aux tile).
-  auto k_step = [&](auto kind_c) __attribute__((always_inline)) {
-    constexpr int KIND = decltype(kind_c)::value;
+  // Neither: steady state (the cursor is inside this tile: every request is issued, nothing else happens).
+  bool a1_ahead = false;
+  int ahead_stores = 0;
+  auto k_step = [&](auto first_c, auto penult_c, auto last_c) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_c)::value, PENULT = decltype(penult_c)::value, LAST = decltype(last_c)::value;
     // phase 1
     read_b(std::integral_constant<int, 0>{}, fb0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
-    if (KIND == 1 && dynamic && threadIdx.x == 0) {
+    if (PENULT && dynamic && threadIdx.x == 0) {
       const unsigned one = 1u, zero = 0u;
       asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zero), "v"(one), "s"(tile_counter) : "memory");
     }
-    if (KIND == 2 && !SPLIT && p.bias != nullptr && n0 + BN2 <= p.N) bias_request();
-    if (KIND == 2 && act_bwd) aux_request(0, c_buf ^ 1);
-    else if (KIND != 2 || r_valid) request(A1);
-    if (KIND == 1) {
+    if (LAST && !SPLIT && p.bias != nullptr && nxt < ntiles) {
+      long long bm0, bn0;
+      tile_origin(nxt, bm0, bn0);
+      if (bn0 + BN2 <= p.N) bias_request(bn0);
+    }
+    if (LAST && act_bwd) aux_request(0, c_buf ^ 1);
+    else if (FIRST ? !a1_ahead : (!LAST || r_valid)) request(A1);
+    if (PENULT) {
       if (nxt < ntiles) set_cursor(nxt);
       else r_valid = false;
     }
@@ -615,22 +639,24 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     // phase 2
     read_b(std::integral_constant<int, 1>{}, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    if (KIND == 0 || r_valid) request(B0);
+    if (!(PENULT || LAST) || r_valid) request(B0);
     phase_barrier();
     multiply(0, 1, fb1);
     phase_barrier();
     // phase 3
     read_a(std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
-    if (KIND == 0 || r_valid) request(A0);
+    if (!(PENULT || LAST) || r_valid) request(A0);
     phase_barrier();
     multiply(1, 1, fb1);
     phase_barrier();
     // phase 4
-    if (KIND == 0 || r_valid) {
+    if (!(PENULT || LAST) || r_valid) {
       request(B1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (!(KIND == 2 && act_bwd)) {
+      if (FIRST && a1_ahead && ahead_stores == 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+      else if (FIRST && a1_ahead && ahead_stores == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (!(LAST && act_bwd)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // end of the stream: whatever is still in flight
     }
     c_buf ^= 1;
@@ -640,8 +666,15 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     multiply(1, 0, fb0);
     phase_barrier();
   };
+  constexpr std::true_type yes{};
+  constexpr std::false_type no{};
 
   // prologue: all of the first k-step and three half-tiles of the second
+  if (!SPLIT && p.bias != nullptr) {
+    long long bm0, bn0;
+    tile_origin(cur, bm0, bn0);
+    if (bn0 + BN2 <= p.N) bias_request(bn0);
+  }
   set_cursor(cur);
   request(B0);
   request(A0);
@@ -660,19 +693,42 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   DPA_STAMP(1);
 
   while (true) {
+    DPA_STAMP(6);
     tile_origin(cur, m0, n0);
+    // Full interior tiles of a plain product leave through the LDS-staged epilogue below (with the bias
+    // already in the accumulators); everything else through the element-wise one.
+    const bool staged = !SPLIT && p.beta == 0.f && p.alpha == 1.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_act)) & 15) == 0;
+    if (staged && p.bias != nullptr) {
+      using lds_u16x4_cptr = const __attribute__((address_space(3))) u16x4*;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const u16x4 raw = *(lds_u16x4_cptr)(lds_base + kBiasOff + (wn + 16 * j + 4 * (lane >> 4)) * 2);
+        f32x4 b;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; ++e) b[e] = BF16::to_f32(raw[e]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i][j] = b;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // The upper wave row runs one barrier behind the lower one inside the k-steps: on every SIMD one
     // wave multiplies while its partner reads LDS and issues requests.
     if (wr == 1) phase_barrier();
+    if (n >= 3) {
+      k_step(yes, no, no);
 #pragma unroll 1
-    for (int t = 0; t < n - 2; ++t) k_step(std::integral_constant<int, 0>{});
-    if (n > 1) k_step(std::integral_constant<int, 1>{});
-    k_step(std::integral_constant<int, 2>{});
+      for (int t = 0; t < n - 3; ++t) k_step(no, no, no);
+      k_step(no, yes, no);
+    } else if (n == 2) {
+      k_step(yes, yes, no);
+    }
+    k_step(no, no, yes);
     if (dynamic && wid == 0) {
       // the counter's answer is in (it is older than the requests a vmcnt(6) leaves in flight)
       asm volatile("" : "+v"(fetched));
@@ -681,6 +737,10 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     }
     if (wr == 0) phase_barrier();
     DPA_STAMP(2);
+    // Every wave is done with the last k-step's buffer: its A1 slot can take the next tile's second k-step
+    // now, ahead of this tile's output stores in the memory queue.
+    a1_ahead = dynamic && r_valid;
+    if (a1_ahead) request(A1);
 
     if (SPLIT) {
       float* ws = p.workspace + static_cast<long long>(blockIdx.y) * p.M * p.N;
@@ -700,8 +760,6 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     // reads) and writes 8 rows x 128 contiguous bytes per store instruction.  Bias and activation are
     // applied in registers first.  The strips lie outside the operand buffers, which already receive the
     // next tile.
-    const bool staged = p.beta == 0.f && m0 + BM2 <= p.M && n0 + BN2 <= p.N && (p.ldc & 7) == 0 &&
-                        ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_act)) & 15) == 0;
     if (staged && act_bwd) {
       // Activation-backward epilogue: C = (alpha*acc) * act'(aux).  Each lane picks the aux values
       // that sit under its accumulators out of the DMA image, writes the result back into the same
@@ -737,7 +795,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
             }
             u16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(p.alpha * a[e] * d[e]);
+            for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(a[e] * d[e]);
             *reinterpret_cast<u16x4*>(cell) = o;  // same lane, same cell: read before write by program order
           }
         if (p.colsum_partial) {
@@ -769,15 +827,13 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     if (staged) {
       using lds_u16x4_ptr = __attribute__((address_space(3))) u16x4*;
       using lds_u32x4_ptr = const __attribute__((address_space(3))) u32x4*;
-      const int r = lane & 15, g = lane >> 4;
+      int l = lane;
+      asm volatile("" : "+v"(l));  // the epilogue's lane constants are derived here, not kept from the top of the kernel
+      const int r = l & 15, g = l >> 4;
       const unsigned mine = lds_base + kStageOff + wid * 2048;
       const unsigned wr_addr = mine + r * 128 + 8 * (g & 1);       // + ((chunk ^ (r & 7)) << 4) per column tile
-      const unsigned rd_addr = mine + (lane >> 3) * 128 + (lane & 7) * 16;
-      const int out_col = ((lane & 7) ^ (lane >> 3)) * 8;
-      if (p.bias == nullptr) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bias_raw[j] = u32x2{0u, 0u};
-      }
+      const unsigned rd_addr = mine + (l >> 3) * 128 + (l & 7) * 16;
+      const int out_col = ((l & 7) ^ (l >> 3)) * 8;
       // one pass per output tensor and 16 rows: the pre-activation (when the backward will need it), then
       // the result.  The activation is a compile-time parameter: selected per element it costs a scalar
       // branch for each of the 128 values a lane owns, more than the arithmetic.
@@ -789,8 +845,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
           u16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float bias_e = __uint_as_float(e & 1 ? bias_raw[j][e >> 1] & 0xffff0000u : bias_raw[j][e >> 1] << 16);
-            o[e] = BF16::from_f32(p.alpha * a[e] + bias_e);
+            o[e] = BF16::from_f32(a[e]);  // alpha == 1 and the bias is in the accumulator on this path
             // the activation sees the pre-activation rounded to bf16, exactly as the unfused path stores and re-reads it
             if (ACT == kActGelu) {
               const int bits = o[e];
@@ -813,7 +868,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       auto emit_all = [&](auto act_c) __attribute__((always_inline)) {
         // this lane's element of the tile's first 8 rows; advanced 16 rows per pass (the pin keeps the
         // compiler from holding all sixteen row pointers in registers at once)
-        const long long first = (m0 + wm + (lane >> 3)) * p.ldc + n0 + wn + out_col;
+        const long long first = (m0 + wm + (l >> 3)) * p.ldc + n0 + wn + out_col;
         u16* c_rows = static_cast<u16*>(p.C) + first;
         u16* p_rows = p.pre_act ? static_cast<u16*>(p.pre_act) + first : nullptr;
         const long long pass_step = 16 * p.ldc;
@@ -832,7 +887,9 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       if (p.act == kActGelu) emit_all(std::integral_constant<int, kActGelu>{});
       else if (p.act == kActRelu) emit_all(std::integral_constant<int, kActRelu>{});
       else emit_all(std::integral_constant<int, kActNone>{});
+      ahead_stores = p.pre_act ? 32 : 16;
     } else {
+      ahead_stores = 0;  // ragged tile: an unknown number of stores, the next wait covers them all
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -847,6 +904,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     if (cur >= ntiles) return;
     const unsigned drawn = __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
     nxt = static_cast<int>(2u * gridDim.x + drawn);
+    set_offsets(cur);  // the cursor is inside this tile
   }
 }
 
@@ -880,7 +938,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 bool gemm_bf16_act_backward_supported(const GemmArgs& a) {
   return gemm_bf16_supported(a) && a.M % BM2 == 0 && a.N % BN2 == 0 && a.K % BK2 == 0 && (a.ldc & 7) == 0 && a.bias == nullptr &&
-         a.pre_act == nullptr && a.beta == 0.f && a.act == kActNone && aligned16(a.C) && aligned16(a.aux) &&
+         a.pre_act == nullptr && a.beta == 0.f && a.alpha == 1.f && a.act == kActNone && aligned16(a.C) && aligned16(a.aux) &&
          (a.aux_mode == kActGelu || a.aux_mode == kActRelu);
 }
 
@@ -921,6 +979,7 @@ bool gemm_bf16_supported(const GemmArgs& a) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
   // 16-byte global loads: contiguous extents and leading dimensions in multiples of 8 elements.
   if (a.lda % 8 || a.ldb % 8) return false;
+  if (a.lda >= (1ll << 22) || a.ldb >= (1ll << 22)) return false;  // tile-relative byte offsets are 32-bit
   if (a.a_kmajor ? (a.K % 8) : (a.M % 8)) return false;
   if (a.b_kmajor ? (a.K % 8) : (a.N % 8)) return false;
   if (a.A && !aligned16(a.A)) return false;
@@ -957,7 +1016,7 @@ bool use_streaming(const GemmArgs& a, long long tiles, bool split) {
   if (split || a.aux_mode != kActNone) return false;
   const long long nk = a.K / BK2;
   const StreamingSetup& s = streaming_setup();
-  return s.counters != nullptr && s.cus > 0 && nk >= 2 && nk <= kStreamingMaxKSteps && tiles >= 3ll * s.cus;
+  return s.counters != nullptr && s.cus > 0 && nk >= 3 && nk <= kStreamingMaxKSteps && tiles >= 3ll * s.cus;
 }
 
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {

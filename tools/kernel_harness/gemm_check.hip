@@ -33,8 +33,8 @@ static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fff
 struct Problem {
   long long M, N, K;
   int ak, bk;  // k-major flags
-  std::vector<unsigned short> hA, hB;
-  unsigned short *A = nullptr, *B = nullptr, *C = nullptr;
+  std::vector<unsigned short> hA, hB, hBias;
+  unsigned short *A = nullptr, *B = nullptr, *C = nullptr, *bias = nullptr;
   float* ws = nullptr;
   GemmArgs args{};
   Problem(long long M_, long long N_, long long K_, int ak_, int bk_, unsigned seed) : M(M_), N(N_), K(K_), ak(ak_), bk(bk_) {
@@ -50,11 +50,20 @@ struct Problem {
     args.lda = ak ? K : M; args.ldb = bk ? K : N; args.ldc = N;
     args.a_kmajor = ak; args.b_kmajor = bk; args.alpha = 1.f;
   }
-  ~Problem() { hipFree(A); hipFree(B); hipFree(C); if (ws) hipFree(ws); }
+  ~Problem() { hipFree(A); hipFree(B); hipFree(C); if (ws) hipFree(ws); if (bias) hipFree(bias); }
+  void add_bias() {
+    std::mt19937 rng(4242);
+    std::uniform_real_distribution<float> d(-4.f, 4.f);
+    hBias.resize(N);
+    for (auto& x : hBias) x = f2bf(d(rng));
+    CK(hipMalloc(&bias, N * 2));
+    CK(hipMemcpy(bias, hBias.data(), N * 2, hipMemcpyHostToDevice));
+    args.bias = bias;
+  }
   // element (m, k) of A / (n, k) of B as stored
   float a(long long m, long long k) const { return bf2f(ak ? hA[m * K + k] : hA[k * M + m]); }
   float b(long long n, long long k) const { return bf2f(bk ? hB[n * K + k] : hB[k * N + n]); }
-  double ref(long long m, long long n) const { double s = 0; for (long long k = 0; k < K; ++k) s += static_cast<double>(a(m, k)) * b(n, k); return s; }
+  double ref(long long m, long long n) const { double s = hBias.empty() ? 0.0 : bf2f(hBias[n]); for (long long k = 0; k < K; ++k) s += static_cast<double>(a(m, k)) * b(n, k); return s; }
   void split(int s) { args.split_k = s; if (s > 1) { CK(hipMalloc(&ws, static_cast<size_t>(s) * M * N * 4)); args.workspace = ws; } }
 };
 
@@ -67,7 +76,7 @@ static void launch_large(const GemmArgs& a, hipStream_t st, bool streaming = fal
   const int tm = static_cast<int>((a.M + 255) / 256), tn = static_cast<int>((a.N + 255) / 256);
   const long long nk = a.K / 64;
   const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);
-  streaming = streaming && !split && nk >= 2;
+  streaming = streaming && !split && nk >= 3;
   if (streaming) CK(hipMemsetAsync(counter, 0, 16, st));
   unsigned* ctr = streaming ? counter : nullptr;
   const dim3 grid(streaming ? std::min(tm * tn, 256) : tm * tn, split ? a.split_k : 1);
@@ -90,9 +99,10 @@ static void launch_large(const GemmArgs& a, hipStream_t st, bool streaming = fal
   else go(std::false_type{}, std::false_type{});
 }
 
-static int check_one(long long M, long long N, long long K, int ak, int bk, int split, int reps, bool streaming = false) {
+static int check_one(long long M, long long N, long long K, int ak, int bk, int split, int reps, bool streaming = false, bool bias = false) {
   Problem p(M, N, K, ak, bk, 1234 + static_cast<unsigned>(M * 7 + N * 3 + K + ak * 2 + bk));
   p.split(split);
+  if (bias) p.add_bias();
   std::vector<unsigned short> out0(M * N), out(M * N);
   int bad = 0, nondet = 0;
   for (int r = 0; r < reps; ++r) {
@@ -119,7 +129,7 @@ static int check_one(long long M, long long N, long long K, int ak, int bk, int 
     if (!(err <= tol)) { if (bad < 5) printf("    mismatch (%lld,%lld): got %.4f ref %.4f\n", m, n, got, ref); ++bad; }
     worst = std::max(worst, err / (std::fabs(ref) + 1.0));
   }
-  printf("%s%s%s M=%lld N=%lld K=%lld split=%d : %s  (bad %d / %lld, worst rel %.3g, nondeterministic runs %d / %d)\n", streaming ? "streaming " : "", ak ? "N" : "T", bk ? "T" : "N",
+  printf("%s%s%s%s M=%lld N=%lld K=%lld split=%d : %s  (bad %d / %lld, worst rel %.3g, nondeterministic runs %d / %d)\n", streaming ? "streaming " : "", bias ? "bias " : "", ak ? "N" : "T", bk ? "T" : "N",
          M, N, K, split, (bad || nondet) ? "FAIL" : "ok", bad, samples, worst, nondet, reps - 1);
   fflush(stdout);
   return (bad || nondet) ? 1 : 0;
@@ -152,9 +162,15 @@ int main(int argc, char** argv) {
     for (const auto& l : layouts)
       for (const auto& s : shapes) fails += check_one(s.M, s.N, s.K, l[0], l[1], s.split, 4);
     // several tiles per workgroup (ids drawn from the counter): more tiles than CUs, 2 .. 48 k-steps, ragged edges
-    const S stream_shapes[] = {{8192, 4096, 128, 1}, {16384, 2304, 192, 1}, {12288, 3072, 768, 1}, {8440, 2312, 256, 1}, {65536, 768, 3072, 1}, {2048, 1024, 512, 1}};
+    const S stream_shapes[] = {{8192, 4096, 256, 1}, {16384, 2304, 192, 1}, {12288, 3072, 768, 1}, {8440, 2312, 256, 1}, {65536, 768, 3072, 1}, {2048, 1024, 512, 1}};
     for (const auto& l : layouts)
       for (const auto& s : stream_shapes) fails += check_one(s.M, s.N, s.K, l[0], l[1], 1, 4, true);
+    // bias (carried in the accumulators of full tiles, added element-wise on ragged ones), both launch modes
+    const S bias_shapes[] = {{512, 768, 320, 1}, {504, 520, 256, 1}, {768, 768, 2048, 4}, {12288, 3072, 768, 1}, {8440, 2312, 256, 1}};
+    for (const auto& s : bias_shapes) {
+      fails += check_one(s.M, s.N, s.K, 1, 1, s.split, 4, false, true);
+      fails += check_one(s.M, s.N, s.K, 1, 0, s.split, 4, true, true);
+    }
     printf(fails ? "FAILED: %d cases\n" : "all cases passed (%d failures)\n", fails);
     return fails ? 1 : 0;
   }
@@ -189,6 +205,8 @@ int main(int argc, char** argv) {
     const long long nwg = ((M + 255) / 256) * ((N + 255) / 256);
     unsigned long long* st; CK(hipMalloc(&st, nwg * 64)); CK(hipMemset(st, 0, nwg * 64));
     p.args.colsum_partial = reinterpret_cast<float*>(st);
+    const bool streaming = argc > 6 && std::string(argv[6]) == "stream";
+    auto launch_large = [&](const GemmArgs& a, hipStream_t st) { ::launch_large(a, st, streaming); };
     for (int i = 0; i < 20; ++i) launch_large(p.args, 0);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -216,6 +234,16 @@ int main(int argc, char** argv) {
            (hi - lo) / (ms * 1e-3) / 1e9);
     const char* names[3] = {"entry -> first k-step landed", "main loop", "epilogue"};
     for (int i = 0; i < 3; ++i) printf("  %-30s median %8.0f  p10 %8.0f  p90 %8.0f cycles\n", names[i], d[i][d[i].size() / 2], d[i][d[i].size() / 10], d[i][d[i].size() * 9 / 10]);
+    {  // last tile of every workgroup: stamps 6 (tile start), 2 (k-steps done), 3 (epilogue done)
+      std::vector<double> kl, ep;
+      for (long long w = 0; w < std::min<long long>(nwg, streaming ? 256 : nwg); ++w) {
+        kl.push_back(static_cast<double>(h[w * 8 + 2] - h[w * 8 + 6]));
+        ep.push_back(static_cast<double>(h[w * 8 + 3] - h[w * 8 + 2]));
+      }
+      std::sort(kl.begin(), kl.end()); std::sort(ep.begin(), ep.end());
+      printf("  last tile per workgroup: k-steps median %.0f cycles (%.0f per k-step), epilogue median %.0f cycles\n", kl[kl.size() / 2], kl[kl.size() / 2] / (K / 64),
+             ep[ep.size() / 2]);
+    }
     printf("  k-steps %lld: main loop %.0f cycles per k-step (MFMA floor 2048)\n", K / 64, d[1][d[1].size() / 2] / (K / 64));
     return 0;
   }

@@ -831,13 +831,19 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       asm volatile("" : "+v"(l));  // the epilogue's lane constants are derived here, not kept from the top of the kernel
       const int r = l & 15, g = l >> 4;
       const unsigned mine = lds_base + kStageOff + wid * 2048;
-      const unsigned wr_addr = mine + r * 128 + 8 * (g & 1);       // + ((chunk ^ (r & 7)) << 4) per column tile
+      // + ((chunk ^ (r & 7)) << 4) per column tile; rows 8 .. 15 swap the 8-byte halves of a chunk, so that the 16
+      // lanes an 8-byte LDS write serves per cycle (rows 0 .. 15 of one column group) cover all 32 banks
+      const unsigned wr_addr = mine + r * 128 + 8 * ((g & 1) ^ (r >> 3));
       const unsigned rd_addr = mine + (l >> 3) * 128 + (l & 7) * 16;
       const int out_col = ((l & 7) ^ (l >> 3)) * 8;
-      // one pass per output tensor and 16 rows: the pre-activation (when the backward will need it), then
+      // One pass per output tensor and 16 rows: the pre-activation (when the backward will need it), then
       // the result.  The activation is a compile-time parameter: selected per element it costs a scalar
-      // branch for each of the 128 values a lane owns, more than the arithmetic.
-      auto emit = [&](u16* out_rows, int i, auto act_c) __attribute__((always_inline)) {
+      // branch for each of the 128 values a lane owns, more than the arithmetic.  A pass writes its 16 x 64
+      // values into the strip (4 x 8 bytes per lane) and reads them back as two 16-byte row pieces; the LDS
+      // serves one wave's requests in order, so the passes need no waits between them and are software-
+      // pipelined: the next pass is converted and written while the row pieces of the current one return,
+      // and only the global stores wait for LDS data.
+      auto convert_write = [&](int i, auto act_c) __attribute__((always_inline)) {
         constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -858,29 +864,46 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
           }
           *(lds_u16x4_ptr)(wr_addr + (((2 * j + (g >> 1)) ^ (r & 7)) << 4)) = o;
         }
-        // the wave reads back only what it wrote itself, and the LDS serves one wave's requests in order
+      };
+      auto read_rows = [&](u32x4 (&v)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const u32x4 v = *(lds_u32x4_ptr)(rd_addr + it * 1024);
-          *reinterpret_cast<u32x4*>(out_rows + static_cast<long long>(8 * it) * p.ldc) = v;
-        }
+        for (int it = 0; it < 2; ++it) v[it] = *(lds_u32x4_ptr)(rd_addr + it * 1024);
+      };
+      auto store_rows = [&](u16* out, int i, const u32x4 (&v)[2]) __attribute__((always_inline)) {
+        // rows 8 .. 15 of a pass keep the two 8-byte halves of every 16-byte chunk swapped (see wr_addr)
+        *reinterpret_cast<u32x4*>(out + static_cast<long long>(16 * i) * p.ldc) = v[0];
+        *reinterpret_cast<u32x4*>(out + static_cast<long long>(16 * i + 8) * p.ldc) = u32x4{v[1][2], v[1][3], v[1][0], v[1][1]};
       };
       auto emit_all = [&](auto act_c) __attribute__((always_inline)) {
-        // this lane's element of the tile's first 8 rows; advanced 16 rows per pass (the pin keeps the
-        // compiler from holding all sixteen row pointers in registers at once)
+        // this lane's element of the tile's first 8 rows
         const long long first = (m0 + wm + (l >> 3)) * p.ldc + n0 + wn + out_col;
         u16* c_rows = static_cast<u16*>(p.C) + first;
         u16* p_rows = p.pre_act ? static_cast<u16*>(p.pre_act) + first : nullptr;
-        const long long pass_step = 16 * p.ldc;
+        constexpr std::integral_constant<int, kActNone> plain{};
+        u32x4 v[2][2];
+        if (p_rows) {
+          // passes: (pre-activation, rows i), (result, rows i), i = 0 .. 7
+          convert_write(0, plain);
+          read_rows(v[0]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (p_rows) emit(p_rows, i, std::integral_constant<int, kActNone>{});
-          emit(c_rows, i, act_c);
-          c_rows += pass_step;
-          asm volatile("" : "+v"(c_rows));
-          if (p_rows) {
-            p_rows += pass_step;
-            asm volatile("" : "+v"(p_rows));
+          for (int q = 0; q < 16; ++q) {
+            if (q + 1 < 16) {
+              if ((q + 1) & 1) convert_write((q + 1) >> 1, act_c);
+              else convert_write((q + 1) >> 1, plain);
+              read_rows(v[(q + 1) & 1]);
+            }
+            store_rows(q & 1 ? c_rows : p_rows, q >> 1, v[q & 1]);
+          }
+        } else {
+          convert_write(0, act_c);
+          read_rows(v[0]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (i + 1 < 8) {
+              convert_write(i + 1, act_c);
+              read_rows(v[(i + 1) & 1]);
+            }
+            store_rows(c_rows, i, v[i & 1]);
           }
         }
       };

@@ -40,7 +40,8 @@ def parse_args(argv=None):
     p.add_argument("--batch-size", type=int, default=None, help="per-GPU batch (default depends on the model)")
     p.add_argument("--seq-len", type=int, default=1024)
     p.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="compute dtype (default bf16; dummy: fp32)")
-    p.add_argument("--linear-impl", default=os.environ.get("BENCH_LINEAR_IMPL", "library"), choices=["auto", "native", "library", "stock"])
+    p.add_argument("--linear-impl", default=os.environ.get("BENCH_LINEAR_IMPL", "native"), choices=["native", "library", "stock"],
+                   help="GPT-2 GEMMs: hand-written MFMA kernels (default); 'library' sends them to the vendor GEMM for A/B runs")
     p.add_argument("--widemlp-gemm", default="native", choices=["native", "library"],
                    help="Wide MLP: forward / input-gradient GEMMs on the hand-written kernel (default) or the vendor library")
     p.add_argument("--attention-impl", default="auto", choices=["auto", "native", "sdpa"], help="GPT-2 attention kernel (ablation)")
@@ -53,8 +54,6 @@ def parse_args(argv=None):
     p.add_argument("--no-busbw", action="store_true", help="skip the all-reduce bus-bandwidth measurement after the timed steps (N > 1)")
     p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
     p.add_argument("--stock", action="store_true", help="comparison run: stock torch ops and torch.optim.AdamW(fused=True)")
-    p.add_argument("--tuned-gemms", action="store_true", help="vendor GEMMs by the shipped TunableOp solution table instead of the library's default heuristic (measured: within 0.5 %% of the default)")
-    p.add_argument("--tune-gemms", default=None, metavar="CSV", help="time all vendor GEMM solutions for the shapes of this run and write the winners to CSV")
     p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph")
     p.add_argument("--json-out", default=None, help="also write the JSON line to this file")
     return p.parse_args(argv)
@@ -143,24 +142,6 @@ def run_rank(rank: int, world_size: int, argv):
     device = dist.get_device()
     if use_gpu:
         torch.cuda.set_device(device)
-        from distributed_pytorch_amd.utils import gemm_tuning
-
-        if args.tune_gemms:
-            gemm_tuning.record_tuned_gemms(args.tune_gemms if world_size == 1 else f"{args.tune_gemms}.rank{rank}")
-            if rank == 0:  # tuning a shape takes a while and prints nothing: keep a sign of life on stderr
-                import sys as _sys
-                import threading as _threading
-                import time as _time
-
-                def _heartbeat():
-                    t0 = _time.time()
-                    while True:
-                        _time.sleep(30)
-                        print(f"[tune-gemms] {_time.time() - t0:.0f}s", file=_sys.stderr, flush=True)
-
-                _threading.Thread(target=_heartbeat, daemon=True).start()
-        elif args.tuned_gemms and not args.stock:
-            gemm_tuning.enable_tuned_gemms()
     torch.manual_seed(0)
 
     model, loss_fn, per_gpu_batch, dtype, info = build_workload(args, device)
@@ -239,7 +220,6 @@ def run_rank(rank: int, world_size: int, argv):
             "optimizer": "torch.optim.AdamW(fused)" if args.stock else "FusedAdamW" + ("+fp32-master" if dtype != torch.float32 else ""),
             "stock_torch_ops": bool(args.stock),
             "linear_impl": args.linear_impl,
-            "vendor_gemm_table": bool(use_gpu and args.tuned_gemms and not (args.stock or args.tune_gemms)),
             "grad_reduce_dtype": (args.reduce_dtype or ("param dtype" if n > 1 else None)),
             "comm": (pg.get_backend() if n > 1 else None),
             "hip_graph": bool(graph is not None),

@@ -295,13 +295,22 @@ void run_gemm(const kernels::GemmArgs& a, int dt, hipStream_t s, const Tensor& l
   kernels::launch_gemm_bf16(a, s);
 }
 
-// Which kernel family a y = x W^T (+b) product of this shape runs on.
+// Whether the MFMA GEMMs take C[M,N] = op(A) op(B)^T with contiguous operands in the given layouts.
+bool gemm_shape_ok(int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, int dt) {
+  kernels::GemmArgs a{};
+  a.M = M; a.N = N; a.K = K; a.lda = a_kmajor ? K : M; a.ldb = b_kmajor ? K : N; a.ldc = N;
+  a.a_kmajor = a_kmajor; a.b_kmajor = b_kmajor;
+  return gemm_path_ok(a, dt);
+}
+
+// Which kernel family a linear layer y = x W^T (+b) of this shape runs on.  "mfma" only when the forward AND both
+// backward products (dW = g^T x with N and K as contiguous extents, dx = g W) fit the MFMA GEMMs' 16-byte
+// vector layout, so a layer never passes its forward and then fails in its backward.
 std::string linear_route(int64_t M, int64_t N, int64_t K, int dt) {
   if (K == 1) return "outer";
   if (N <= 16) return "skinny";
-  kernels::GemmArgs a{};
-  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N; a.a_kmajor = 1; a.b_kmajor = 1;
-  return gemm_path_ok(a, dt) ? "mfma" : "unsupported";
+  const bool ok = gemm_shape_ok(M, N, K, true, true, dt) && gemm_shape_ok(N, K, M, false, false, dt) && gemm_shape_ok(M, K, N, true, false, dt);
+  return ok ? "mfma" : "unsupported";
 }
 
 // y = act(x W^T + b).  x: [M, K], W: [N, K], b: [N] or None.  Returns (y, pre_activation or None).
@@ -647,6 +656,9 @@ void init_ops(py::module_& m) {
   m.def("xent_forward", &xent_forward, py::arg("logits"), py::arg("targets"), py::arg("n_classes") = -1, py::arg("ignore_index") = -100);
   m.def("xent_backward", &xent_backward, py::arg("logits"), py::arg("targets"), py::arg("row_lse"), py::arg("grad_out"), py::arg("metrics"),
         py::arg("mean") = true, py::arg("n_classes") = -1, py::arg("ignore_index") = -100, py::arg("inplace") = false);
+  m.def("gemm_supported", [](int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor, const std::string& dtype) {
+    return gemm_shape_ok(M, N, K, a_kmajor, b_kmajor, dtype == "float32" ? kernels::kF32 : (dtype == "bfloat16" ? kernels::kBF16 : kernels::kF16));
+  });
   m.def("linear_route", [](int64_t M, int64_t N, int64_t K, const std::string& dtype) {
     const int dt = dtype == "float32" ? kernels::kF32 : (dtype == "bfloat16" ? kernels::kBF16 : kernels::kF16);
     return linear_route(M, N, K, dt);

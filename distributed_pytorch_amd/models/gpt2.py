@@ -9,10 +9,9 @@ every logits row is 16-byte aligned, gradient written in place over the logits),
 optimizer (FusedAdamW).  Attention runs on the native flash-attention kernels directly on the
 packed q|k|v projection (``attention_impl="sdpa"`` selects torch's kernel instead).
 
-``linear_impl``: ``"native"`` routes every projection through the hand-written MFMA GEMM;
-``"library"`` runs the plain GEMMs on the vendor library and everything around them
-(activation backward, bias gradients) on our kernels; ``"auto"`` uses the native GEMM where
-it fuses an epilogue (the GELU up-projection) and the library elsewhere; ``"stock"`` is
+``linear_impl``: ``"native"`` (default) routes every GEMM of the model -- projections, the fused MLP /
+attention / lm-head nodes, all weight and input gradients -- through the hand-written MFMA GEMM;
+``"library"`` sends the plain GEMMs to the vendor library for A/B measurements; ``"stock"`` is
 unmodified torch (``F.linear`` / ``F.gelu``), the comparison baseline.
 """
 from __future__ import annotations
@@ -41,7 +40,7 @@ class GPT2Config:
     n_embd: int = 768
     bias: bool = True
     vocab_pad_multiple: int = 64
-    linear_impl: str = "auto"     # native | library | auto
+    linear_impl: str = "native"   # native | library (A/B only) | stock
     inplace_loss_backward: bool = True
     native_ops: bool = True       # False: stock torch layer norm / GELU / cross-entropy (comparison baseline)
     attention_impl: str = "auto"  # auto | native | sdpa
@@ -75,10 +74,9 @@ class _Proj(nn.Linear):
     def forward(self, x, skip_bias: bool = False):
         """``skip_bias``: leave the bias out (the caller adds it inside the next fused add + layer norm)."""
         bias = None if skip_bias else self.bias
-        use_native = self.impl == "native" or (self.impl == "auto" and self.act is not None)
-        if use_native and x.is_cuda:
+        if self.impl == "native" and x.is_cuda:
             return linear_bias_act(x, self.weight, bias, self.act)
-        if self.impl in ("library", "auto") and x.is_cuda:
+        if self.impl == "library" and x.is_cuda:
             return library_linear_bias_act(x, self.weight, bias, self.act)
         y = F.linear(x, self.weight, bias)
         if self.act == "gelu":
@@ -94,12 +92,13 @@ class CausalSelfAttention(nn.Module):
         assert cfg.n_embd % cfg.n_head == 0
         self.n_head = cfg.n_head
         self.impl = cfg.attention_impl if cfg.native_ops else "sdpa"
-        self.fused = cfg.fused_qkv_attention and cfg.native_ops and cfg.linear_impl == "library" and cfg.bias and self.impl != "sdpa"
+        self.gemm_impl = cfg.linear_impl
+        self.fused = cfg.fused_qkv_attention and cfg.native_ops and cfg.linear_impl in ("native", "library") and cfg.bias and self.impl != "sdpa"
         self.c_attn = _Proj(cfg.n_embd, 3 * cfg.n_embd, cfg.bias, cfg.linear_impl)
         self.c_proj = _Proj(cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
 
     def forward(self, x, skip_bias: bool = False):
-        y = projected_causal_attention(x, self.c_attn.weight, self.c_attn.bias, self.n_head) if self.fused else None
+        y = projected_causal_attention(x, self.c_attn.weight, self.c_attn.bias, self.n_head, impl=self.gemm_impl) if self.fused else None
         if y is None:
             y = causal_attention_qkvpacked(self.c_attn(x), self.n_head, impl=self.impl)
         return self.c_proj(y, skip_bias)
@@ -108,7 +107,8 @@ class CausalSelfAttention(nn.Module):
 class MLP(nn.Module):
     def __init__(self, cfg: GPT2Config):
         super().__init__()
-        self.fused = cfg.fused_mlp and cfg.native_ops and cfg.linear_impl == "library" and cfg.bias
+        self.gemm_impl = cfg.linear_impl
+        self.fused = cfg.fused_mlp and cfg.native_ops and cfg.linear_impl in ("native", "library") and cfg.bias
         self.c_fc = _Proj(cfg.n_embd, 4 * cfg.n_embd, cfg.bias, cfg.linear_impl, act="gelu")
         self.c_proj = _Proj(4 * cfg.n_embd, cfg.n_embd, cfg.bias, cfg.linear_impl)
 
@@ -116,7 +116,8 @@ class MLP(nn.Module):
         if self.fused and x.is_cuda:
             # both layers as one autograd node: the backward fuses GELU' and the c_fc bias gradient into
             # the epilogue of c_proj's input-gradient GEMM
-            return fused_mlp(x, self.c_fc.weight, self.c_fc.bias, self.c_proj.weight, None if skip_bias else self.c_proj.bias, "gelu")
+            return fused_mlp(x, self.c_fc.weight, self.c_fc.bias, self.c_proj.weight, None if skip_bias else self.c_proj.bias, "gelu",
+                             impl=self.gemm_impl)
         return self.c_proj(self.c_fc(x), skip_bias)
 
 
@@ -204,9 +205,10 @@ class GPT2(nn.Module):
             return F.cross_entropy(lg.float(), targets.reshape(-1))
         if self.cfg.fused_lm_head_loss:
             # vocabulary projection + loss + d(logits) as one node: the logits cross HBM twice, not three times
-            r = projection_cross_entropy(x, self.wte.weight, targets, n_classes=self.cfg.vocab_size)
+            r = projection_cross_entropy(x, self.wte.weight, targets, n_classes=self.cfg.vocab_size,
+                                         impl="library" if self.cfg.linear_impl == "library" else "native")
         else:
-            logits = F.linear(x, self.wte.weight)  # [B, T, padded vocab]: plain GEMM, vendor library
+            logits = linear_bias_act(x, self.wte.weight) if self.cfg.linear_impl == "native" else F.linear(x, self.wte.weight)
             r = softmax_cross_entropy(logits.view(B * T, -1), targets.reshape(-1), n_classes=self.cfg.vocab_size,
                                       inplace_backward=self.cfg.inplace_loss_backward)
         self.last_correct, self.last_metrics = r.correct, r.metrics

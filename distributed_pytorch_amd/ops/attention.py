@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _ext
+from . import gemm
 
 
 class _FlashQKV(torch.autograd.Function):
@@ -47,23 +48,22 @@ class _ProjFlashQKV(torch.autograd.Function):
     gradient is not re-read by a column-sum pass."""
 
     @staticmethod
-    def forward(ctx, x2, w, b, B, T, n_head, scale):
-        qkv = F.linear(x2, w, b).view(B, T, w.shape[0])
+    def forward(ctx, x2, w, b, B, T, n_head, scale, impl):
+        qkv = gemm.nt(x2, w, b, impl).view(B, T, w.shape[0])
         o, lse = _ext.C().attention_forward(qkv, n_head, scale)
         ctx.save_for_backward(x2, w, qkv, o, lse)
-        ctx.n_head, ctx.scale = n_head, scale
+        ctx.n_head, ctx.scale, ctx.impl = n_head, scale, impl
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        from .mlp import _wgrad
         C = _ext.C()
         x2, w, qkv, o, lse = ctx.saved_tensors
         d_o = d_o if d_o.is_contiguous() else d_o.contiguous()
         dqkv, db = C.attention_backward(d_o, qkv, o, lse, ctx.n_head, ctx.scale, True)
         g = dqkv.view(-1, dqkv.shape[-1])
-        dx = g @ w if ctx.needs_input_grad[0] else None
-        return dx, _wgrad(C, g, x2), db, None, None, None, None
+        dx = gemm.nn(g, w, ctx.impl) if ctx.needs_input_grad[0] else None
+        return dx, gemm.tn(g, x2, ctx.impl), db, None, None, None, None, None
 
 
 def native_attention_supported(qkv: torch.Tensor, n_head: int) -> bool:
@@ -78,7 +78,7 @@ def native_attention_supported(qkv: torch.Tensor, n_head: int) -> bool:
 
 
 def projected_causal_attention(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], n_head: int,
-                               softmax_scale: Optional[float] = None) -> Optional[torch.Tensor]:
+                               softmax_scale: Optional[float] = None, impl: str = "native") -> Optional[torch.Tensor]:
     """``attention(x @ weight.T + bias)`` for x [B, T, C_in] and a [3*C, C_in] q|k|v projection, as one
     autograd node on the native kernels.  Returns None when the shape / dtype is not covered (the
     caller then runs the projection and ``causal_attention_qkvpacked`` separately)."""
@@ -92,7 +92,7 @@ def projected_causal_attention(x: torch.Tensor, weight: torch.Tensor, bias: Opti
     scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(hd)
     x2 = x.reshape(B * T, x.shape[-1])
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
-    return _ProjFlashQKV.apply(x2, weight, bias, B, T, n_head, scale)
+    return _ProjFlashQKV.apply(x2, weight, bias, B, T, n_head, scale, impl)
 
 
 def causal_attention_qkvpacked(qkv: torch.Tensor, n_head: int, softmax_scale: Optional[float] = None,

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _ext
+from . import gemm
 
 
 class XentResult(NamedTuple):
@@ -62,11 +63,12 @@ class _ProjectionXent(torch.autograd.Function):
     [tokens, vocabulary] tensor."""
 
     @staticmethod
-    def forward(ctx, x2, weight, targets, reduction: str, ignore_index: int, n_classes: int):
+    def forward(ctx, x2, weight, targets, reduction: str, ignore_index: int, n_classes: int, impl: str):
         C = _ext.C()
-        logits = torch.mm(x2, weight.t())  # plain GEMM: vendor library
+        logits = gemm.nt(x2, weight, None, impl)
         correct, metrics = C.xent_fused(logits, targets, n_classes, ignore_index, reduction == "mean")
         ctx.save_for_backward(x2, weight, logits)  # `logits` now holds d loss / d logits for a unit upstream gradient
+        ctx.impl = impl
         ctx.mark_non_differentiable(correct, metrics)
         loss = (metrics[3] if reduction == "mean" else metrics[0]).clone()
         return loss, correct, metrics
@@ -77,21 +79,15 @@ class _ProjectionXent(torch.autograd.Function):
         g = dloss.detach().to(dlogits.dtype)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dlogits, weight).mul_(g)
+            dx = gemm.nn(dlogits, weight, ctx.impl).mul_(g)
         if ctx.needs_input_grad[1]:
-            # [vocabulary, K] with the whole token count as contraction: the native kernel where it splits the
-            # contraction to fill the last round of tiles, the vendor GEMM otherwise
-            C = _ext.C()
-            if (dlogits.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
-                    and C.gemm_bf16_split_k(dlogits.shape[1], x2.shape[1], dlogits.shape[0], False, False) > 1):
-                dw = C.gemm(dlogits, x2, False, False).mul_(g)
-            else:
-                dw = torch.mm(dlogits.t(), x2).mul_(g)
-        return dx, dw, None, None, None, None
+            # [vocabulary, K] with the whole token count as contraction
+            dw = gemm.tn(dlogits, x2, ctx.impl).mul_(g)
+        return dx, dw, None, None, None, None, None
 
 
 def projection_cross_entropy(x: torch.Tensor, weight: torch.Tensor, targets: torch.Tensor, reduction: str = "mean",
-                             ignore_index: int = -100, n_classes: Optional[int] = None) -> XentResult:
+                             ignore_index: int = -100, n_classes: Optional[int] = None, impl: str = "native") -> XentResult:
     """Cross-entropy of ``x @ weight.T`` (``x``: [..., K], ``weight``: [C, K]) against ``targets``.
 
     On the GPU the logits exist only inside the op: they are written by the GEMM, turned into
@@ -107,7 +103,7 @@ def projection_cross_entropy(x: torch.Tensor, weight: torch.Tensor, targets: tor
                 and nc > 64 and _ext.have_C())
     if not fused_ok:
         return softmax_cross_entropy(F.linear(x2, weight), t1, reduction, ignore_index, nc, inplace_backward=True)
-    loss, correct, metrics = _ProjectionXent.apply(x2.contiguous(), weight, t1.contiguous(), reduction, ignore_index, nc)
+    loss, correct, metrics = _ProjectionXent.apply(x2.contiguous(), weight, t1.contiguous(), reduction, ignore_index, nc, impl)
     return XentResult(loss, correct, metrics)
 
 

@@ -88,9 +88,9 @@ class _LinearBiasAct(torch.autograd.Function):
 
 
 class _LibraryGemmLinear(torch.autograd.Function):
-    """Plain GEMMs on the vendor library (hipBLASLt behind torch.mm / addmm), everything around
-    them on our kernels: activation backward fused with the bias gradient in one pass over dy,
-    bias gradient as a deterministic two-stage column sum."""
+    """A/B comparison path only (``impl="library"``): the three GEMMs on the vendor library behind
+    torch.mm / addmm, everything around them (activation backward fused with the bias gradient in one
+    pass over dy, deterministic two-stage column sum) on our kernels."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act: int):
@@ -114,14 +114,7 @@ class _LibraryGemmLinear(torch.autograd.Function):
             if ctx.has_bias:
                 db = C.colsum(dy)
         dx = g @ weight if ctx.needs_input_grad[0] else None
-        # Weight gradient: [N_out, K_in] is a handful of output tiles with the whole token count as
-        # contraction length.  Where the native GEMM would split the contraction over the chip
-        # (few tiles, long K) it is the faster kernel; otherwise the vendor GEMM runs.
-        if (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and x.is_contiguous()
-                and C.gemm_bf16_split_k(g.shape[1], x.shape[1], g.shape[0], False, False) > 1):
-            dw = C.gemm(g, x, False, False)
-        else:
-            dw = g.t() @ x
+        dw = g.t() @ x
         return dx, dw, db, None
 
 
@@ -164,9 +157,8 @@ def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 class Linear(nn.Linear):
     """``nn.Linear`` (same parameters, same ``state_dict`` keys) with an optional fused
-    activation.  ``impl="native"`` computes everything on the hand-written kernels;
-    ``impl="library"`` sends the forward and input-gradient GEMMs to the vendor library and keeps the
-    activation backward, bias gradient and split-K weight gradient on ours."""
+    activation.  ``impl="native"`` (default) computes everything on the hand-written kernels;
+    ``impl="library"`` sends the GEMMs to the vendor library for A/B measurements."""
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True, act=None, device=None, dtype=None,
                  impl: str = "native"):

@@ -7,51 +7,40 @@ across the layer boundary: the input-gradient GEMM of ``proj`` applies the activ
 of ``fc`` in its epilogue and accumulates ``fc``'s bias gradient on the way out, so the
 [tokens, 4*C] gradient is written once and never re-read by an elementwise pass.
 
-    forward   pre, h = x W_fc^T + b_fc, act(.)   native MFMA GEMM, both outputs from one epilogue (GELU;
-                                                   vendor GEMM + elementwise pass for other activations)
-              y   = h W_proj^T (+ b_proj)  vendor GEMM
-    backward  g, db_fc = (dy W_proj) * act'(pre), colsum(.)   native MFMA GEMM, fused epilogue
-              dW_proj  = dy^T h                                native split-K GEMM
-              dx       = g W_fc                                vendor GEMM
-              dW_fc    = g^T x                                 native split-K GEMM
+    forward   pre, h = x W_fc^T + b_fc, act(.)   MFMA GEMM, both outputs from one epilogue (GELU; GEMM + elementwise
+                                                   pass for other activations)
+              y   = h W_proj^T (+ b_proj)  MFMA GEMM
+    backward  g, db_fc = (dy W_proj) * act'(pre), colsum(.)   MFMA GEMM, fused epilogue
+              dW_proj  = dy^T h                                split-K MFMA GEMM
+              dx       = g W_fc                                MFMA GEMM
+              dW_fc    = g^T x                                 split-K MFMA GEMM
+
+``impl="library"`` sends the three plain products to the vendor GEMM (A/B measurements only).
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
 import torch.nn.functional as F
 
 from .. import _ext
-from .linear import ACT_GELU, ACT_RELU, _act_code, _torch_act, library_linear_bias_act
-
-
-# Forward of the first layer with a GELU: native MFMA GEMM with bias + GELU in the epilogue and both the
-# activation and the pre-activation as outputs (True), or vendor GEMM followed by an elementwise pass (False).
-# Measured on GPT-2 small, batch 256, same GPU: 1029 vs 1024 samples/s with the table-lookup GELU epilogue
-# (979 vs 982 before it, when the epilogue evaluated erf per element).
-NATIVE_FC_FORWARD = os.environ.get("DIST_MLP_NATIVE_FC", "1") != "0"
-
-
-def _wgrad(C, g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW = g^T x: native split-K kernel where it splits the contraction, vendor GEMM otherwise."""
-    if x.is_contiguous() and g.is_contiguous() and C.gemm_bf16_split_k(g.shape[1], x.shape[1], g.shape[0], False, False) > 1:
-        return C.gemm(g, x, False, False)
-    return g.t() @ x
+from . import gemm
+from .linear import ACT_GELU, ACT_RELU, _act_code, _torch_act, linear_bias_act
 
 
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, w_fc, b_fc, w_proj, b_proj, act: int):
-        if NATIVE_FC_FORWARD and act == ACT_GELU:
-            # one native GEMM writes the activation and the pre-activation from its epilogue
+    def forward(ctx, x2, w_fc, b_fc, w_proj, b_proj, act: int, impl: str):
+        if act == ACT_GELU:
+            # one GEMM writes the activation and the pre-activation from its epilogue
             h, pre = _ext.C().linear_forward(x2, w_fc, b_fc, act, True)
         else:
-            pre = F.linear(x2, w_fc, b_fc)
+            pre = gemm.nt(x2, w_fc, b_fc, impl)
             h = _torch_act(pre, act)
-        y = F.linear(h, w_proj, b_proj)
+        y = gemm.nt(h, w_proj, b_proj, impl)
         ctx.act = act
+        ctx.impl = impl
         ctx.has_b_proj = b_proj is not None
         ctx.save_for_backward(x2, w_fc, w_proj, pre if act == ACT_GELU else h, h)
         return y
@@ -62,11 +51,11 @@ class _FusedMLP(torch.autograd.Function):
         x2, w_fc, w_proj, aux, h = ctx.saved_tensors
         dy = dy.contiguous()
         g, db_fc = C.dgrad_act_backward(dy, w_proj, aux, ctx.act, True)
-        dw_proj = _wgrad(C, dy, h)
+        dw_proj = gemm.tn(dy, h, ctx.impl)
         db_proj = C.colsum(dy) if ctx.has_b_proj else None
-        dx = g @ w_fc if ctx.needs_input_grad[0] else None
-        dw_fc = _wgrad(C, g, x2)
-        return dx, dw_fc, db_fc, dw_proj, db_proj, None
+        dx = gemm.nn(g, w_fc, ctx.impl) if ctx.needs_input_grad[0] else None
+        dw_fc = gemm.tn(g, x2, ctx.impl)
+        return dx, dw_fc, db_fc, dw_proj, db_proj, None, None
 
 
 def fused_mlp_supported(x: torch.Tensor, w_fc: torch.Tensor, b_fc, w_proj: torch.Tensor, act) -> bool:
@@ -81,7 +70,7 @@ def fused_mlp_supported(x: torch.Tensor, w_fc: torch.Tensor, b_fc, w_proj: torch
 
 
 def fused_mlp(x: torch.Tensor, w_fc: torch.Tensor, b_fc: Optional[torch.Tensor], w_proj: torch.Tensor,
-              b_proj: Optional[torch.Tensor], act="gelu") -> torch.Tensor:
+              b_proj: Optional[torch.Tensor], act="gelu", impl: str = "native") -> torch.Tensor:
     """``act(x @ w_fc.T + b_fc) @ w_proj.T (+ b_proj)`` for x of shape ``[..., K]``.
 
     Falls back to the two separate linear ops when the shapes do not fill whole 256x256 tiles or the
@@ -90,10 +79,10 @@ def fused_mlp(x: torch.Tensor, w_fc: torch.Tensor, b_fc: Optional[torch.Tensor],
     code = _act_code(act)
     if not fused_mlp_supported(x, w_fc, b_fc, w_proj, code):
         if x.is_cuda:
-            return library_linear_bias_act(library_linear_bias_act(x, w_fc, b_fc, code), w_proj, b_proj, None)
+            return linear_bias_act(linear_bias_act(x, w_fc, b_fc, code), w_proj, b_proj, None)
         return F.linear(_torch_act(F.linear(x, w_fc, b_fc), code), w_proj, b_proj)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
-    y = _FusedMLP.apply(x2, w_fc, b_fc, w_proj, b_proj, code)
+    y = _FusedMLP.apply(x2, w_fc, b_fc, w_proj, b_proj, code, impl)
     return y.reshape(*lead, w_proj.shape[0])

@@ -186,13 +186,9 @@ def test_launcher_refuses_more_ranks_than_gpus_unless_sharing_is_requested(monke
     assert all(e["MASTER_ADDR"] == "127.0.0.1" and e["DIST_STORE_HOSTED"] == "1" for e in calls["env"])
 
 
-def test_gemm_tuning_is_inert_without_a_gpu_and_profile_summaries_parse(tmp_path):
+def test_profile_summaries_parse(tmp_path):
     from distributed_pytorch_amd.bench import profile
-    from distributed_pytorch_amd.utils import gemm_tuning
 
-    assert os.path.isfile(gemm_tuning.default_table())
-    if not torch.cuda.is_available():
-        assert gemm_tuning.enable_tuned_gemms() is False
     # counter CSV in rocprofv3's layout -> per-kernel averages and derived MFMA utilisation
     p = tmp_path / "c.csv"
     hdr = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"

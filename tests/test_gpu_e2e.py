@@ -104,7 +104,7 @@ def test_gpt2_with_fused_nodes_under_the_reducer_matches_plain_training(rccl_gro
     from distributed_pytorch_amd.ops import FusedAdamW
     from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
 
-    cfg = GPT2Config(block_size=256, vocab_size=1000, n_layer=2, n_head=2, n_embd=128, linear_impl="library")
+    cfg = GPT2Config(block_size=256, vocab_size=1000, n_layer=2, n_head=2, n_embd=128)
     torch.manual_seed(0)
     plain = GPT2(cfg).to(DEV).bfloat16()
     twin = GPT2(cfg).to(DEV).bfloat16()

@@ -52,36 +52,59 @@ def test_gpt2_deferred_residual_structure_equals_plain_blocks():
     torch.testing.assert_close(a(idx, tgt), b(idx, tgt), rtol=1e-6, atol=1e-6)
 
 
-def _cos(a, b):
+def _rel_l2(a, b):
     a, b = a.flatten().double(), b.flatten().double()
-    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+    return float((a - b).norm() / (b.norm() + 1e-30))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["library", "native", "auto", "no_fuse_add_norm", "sdpa"])
+@pytest.mark.parametrize("variant", ["native", "library", "no_fuse_add_norm", "sdpa", "unfused_nodes"])
 def test_gpt2_gpu_kernel_configurations_match_stock_torch(variant):
     """bf16 on the GPU: every configuration of native kernels against unmodified torch ops with the
-    same weights -- loss within bf16 tolerance, every parameter gradient pointing the same way."""
+    same weights -- loss within bf16 tolerance, every parameter gradient close in relative L2 norm."""
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    kw = dict(linear_impl="library")
-    if variant in ("library", "native", "auto"):
-        kw = dict(linear_impl=variant)
+    kw = dict(linear_impl="native")
+    if variant == "library":
+        kw = dict(linear_impl="library")
     elif variant == "no_fuse_add_norm":
         kw["fuse_add_norm"] = False
     elif variant == "sdpa":
         kw["attention_impl"] = "sdpa"
+    elif variant == "unfused_nodes":
+        kw.update(fused_mlp=False, fused_qkv_attention=False, fused_lm_head_loss=False)
     ours = GPT2(_tiny(**kw)).to(dev, torch.bfloat16)
     stock = GPT2(_tiny(linear_impl="stock", native_ops=False)).to(dev, torch.bfloat16)
     stock.load_state_dict(ours.state_dict())
     idx, tgt = _batch(ours.cfg, B=4, T=256, device=dev)
     lo, ls = ours(idx, tgt), stock(idx, tgt)
-    assert abs(float(lo.detach()) - float(ls.detach())) < 3e-2 * abs(float(ls.detach()))
+    assert abs(float(lo.detach()) - float(ls.detach())) < 1e-2 * abs(float(ls.detach()))
     lo.backward()
     ls.backward()
     for (n, p), q in zip(ours.named_parameters(), stock.parameters()):
         assert p.grad is not None and torch.isfinite(p.grad.float()).all(), n
-        assert _cos(p.grad, q.grad) > 0.98, (n, _cos(p.grad, q.grad))
+        # both sides compute in bf16 with different summation orders: compare in relative L2 norm
+        assert _rel_l2(p.grad.float(), q.grad.float()) < 6e-2, (n, _rel_l2(p.grad.float(), q.grad.float()))
+
+
+@pytest.mark.gpu
+def test_gpt2_benchmark_width_matches_fp32_torch():
+    """The benchmark's layer shapes (768 wide, 12 heads, 1024 tokens; two layers, eight sequences) on the
+    native kernels in bf16 against stock torch ops in fp32 on the same weights: loss within 1 %, every
+    parameter gradient within 3 % in relative L2 norm."""
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    cfg = dict(block_size=1024, vocab_size=50257, n_layer=2, n_head=12, n_embd=768)
+    ours = GPT2(GPT2Config(**cfg)).to(dev, torch.bfloat16)
+    ref = GPT2(GPT2Config(linear_impl="stock", native_ops=False, **cfg)).to(dev, torch.float32)
+    ref.load_state_dict({k: v.float() for k, v in ours.state_dict().items()})
+    idx, tgt = _batch(ours.cfg, B=8, T=1024, device=dev)
+    lo, lr_ = ours(idx, tgt), ref(idx, tgt)
+    assert abs(float(lo.detach()) - float(lr_.detach())) < 1e-2 * abs(float(lr_.detach())), (float(lo), float(lr_))
+    lo.backward()
+    lr_.backward()
+    worst = max((_rel_l2(p.grad.float(), q.grad), n) for (n, p), q in zip(ours.named_parameters(), ref.parameters()))
+    assert worst[0] < 3e-2, worst
 
 
 @pytest.mark.gpu

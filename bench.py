@@ -53,6 +53,10 @@ def parse_args(argv=None):
     p.add_argument("--bucket-mb", type=float, default=None)
     p.add_argument("--no-busbw", action="store_true", help="skip the all-reduce bus-bandwidth measurement after the timed steps (N > 1)")
     p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
+    p.add_argument("--force-ddp", action="store_true",
+                   help="N = 1: create the process group and wrap the model in the reducer anyway (one-rank RCCL all-reduces on the "
+                        "communication stream), to profile the overlap machinery on a single GPU")
+    p.add_argument("--trace", action="store_true", help="emit roctx ranges (forward / backward / optimizer) for rocprofv3 --marker-trace")
     p.add_argument("--stock", action="store_true", help="comparison run: stock torch ops and torch.optim.AdamW(fused=True)")
     p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph")
     p.add_argument("--json-out", default=None, help="also write the JSON line to this file")
@@ -127,6 +131,12 @@ def build_workload(args, device):
 # --------------------------------------------------------------------------- one rank
 def run_rank(rank: int, world_size: int, argv):
     args = parse_args(argv)
+    hang_s = os.environ.get("DIST_HANG_DUMP_S", "")
+    if hang_s not in ("", "0"):
+        # a stuck run prints the Python stack of every thread (repeatedly) instead of sitting silent
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(hang_s), repeat=True, file=sys.stderr)
     import torch
 
     import distributed as dist
@@ -137,8 +147,13 @@ def run_rank(rank: int, world_size: int, argv):
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         _ext.C()  # the HIP extension is mandatory on a GPU box
-    if world_size > 1:
-        dist.init_process_group(rank, world_size, args.backend)
+    distributed_run = world_size > 1 or args.force_ddp
+    if distributed_run:
+        if world_size <= 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                os.environ["MASTER_PORT"] = str(dist.find_free_port())
+        dist.init_process_group(rank, max(world_size, 1), args.backend)
     device = dist.get_device()
     if use_gpu:
         torch.cuda.set_device(device)
@@ -150,17 +165,32 @@ def run_rank(rank: int, world_size: int, argv):
         ddp_kwargs["reduce_dtype"] = args.reduce_dtype
     if args.bucket_mb:
         ddp_kwargs["bucket_cap_mb"] = args.bucket_mb
-    model = dist.prepare_ddp_model(model, device_ids=[device.index if device.type == "cuda" else None], **ddp_kwargs)
+    if args.force_ddp and world_size <= 1:
+        from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+        model = DistributedDataParallel(model, **ddp_kwargs)
+    else:
+        model = dist.prepare_ddp_model(model, device_ids=[device.index if device.type == "cuda" else None], **ddp_kwargs)
     if args.stock:
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, fused=use_gpu)
     else:
         opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, master_weights=(dtype != torch.float32))
 
+    if args.trace:
+        from distributed_pytorch_amd.utils.timer import range as trace_range
+    else:
+        import contextlib
+
+        trace_range = lambda _name: contextlib.nullcontext()
+
     def train_step():
-        loss = loss_fn(model)
+        with trace_range("forward"):
+            loss = loss_fn(model)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
+        with trace_range("backward"):
+            loss.backward()
+        with trace_range("optimizer"):
+            opt.step()
         return loss
 
     def sync():
@@ -188,7 +218,8 @@ def run_rank(rank: int, world_size: int, argv):
     sync()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device if (world_size > 1 and pg.get_backend() == "rccl") else "cpu")
+    on_rccl = distributed_run and pg.get_backend() == "rccl"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if on_rccl else "cpu")
     if world_size > 1:
         pg.all_reduce(t, "max")
     elapsed = float(t.item())
@@ -221,7 +252,7 @@ def run_rank(rank: int, world_size: int, argv):
             "stock_torch_ops": bool(args.stock),
             "linear_impl": args.linear_impl,
             "grad_reduce_dtype": (args.reduce_dtype or ("param dtype" if n > 1 else None)),
-            "comm": (pg.get_backend() if n > 1 else None),
+            "comm": (pg.get_backend() if distributed_run else None),
             "hip_graph": bool(graph is not None),
         },
         "tokens_per_sec": round(samples_per_sec * info["tokens_per_sample"], 1),
@@ -229,11 +260,18 @@ def run_rank(rank: int, world_size: int, argv):
         "final_loss": round(final_loss, 5),
         "first_loss": round(float(first_loss.detach().float().item()), 5) if first_loss is not None else None,
     }
-    if world_size > 1 and use_gpu and pg.get_backend() == "rccl" and not args.no_busbw:
-        # After the timed region: all-reduce bus bandwidth at the reducer's bucket size and at 256 MiB, on the
-        # reducer's own path (communication stream + event fences).  Never allowed to cost the result line.
+    if use_gpu and on_rccl and not args.no_busbw:
+        # After the timed region, never allowed to cost the result line:
+        #  * overlap accounting over three extra steps: run time of the bucket all-reduces on the communication
+        #    stream and how much of it the compute stream had to wait for (the part backward did not hide);
+        #  * all-reduce bus bandwidth over bucket-sized messages, on the reducer's own path (communication
+        #    stream + event fences), so the bucket size can be read off the curve.
         try:
-            result["allreduce_busbw_gbps"] = _allreduce_busbw(pg, dist, device, world_size)
+            result.update(_overlap_report(pg, step, device, model))
+        except Exception as exc:  # noqa: BLE001 - diagnostic extra only
+            result["exposed_comm_ms"] = f"failed: {type(exc).__name__}: {exc}"
+        try:
+            result["allreduce_busbw_gbps"] = _allreduce_busbw(pg, dist, device, max(world_size, 1))
         except Exception as exc:  # noqa: BLE001 - diagnostic extra only
             result["allreduce_busbw_gbps"] = f"failed: {type(exc).__name__}: {exc}"
     if use_gpu:
@@ -248,7 +286,31 @@ def run_rank(rank: int, world_size: int, argv):
     dist.cleanup()
 
 
-def _allreduce_busbw(pg, dist, device, world_size, sizes_mb=(64, 256), iters=10):
+def _overlap_report(pg, step, device, model, n_steps=3):
+    """Mean per-step communication-stream busy time, exposed (not overlapped) time and collective count."""
+    import torch
+
+    comm = pg.get_comm()
+    torch.cuda.synchronize(device)
+    comm.set_timing(True)
+    busy = exposed = ops = 0.0
+    try:
+        for _ in range(n_steps):
+            step()
+            torch.cuda.synchronize(device)
+            b, e, n = comm.read_timing()
+            busy, exposed, ops = busy + b, exposed + e, ops + n
+    finally:
+        comm.set_timing(False)
+    out = {"comm_busy_ms": round(busy / n_steps, 3), "exposed_comm_ms": round(exposed / n_steps, 3),
+           "collectives_per_step": round(ops / n_steps, 1)}
+    if hasattr(model, "bucket_sizes"):
+        out["bucket_mib"] = [round(b / 2**20, 1) for b in model.bucket_sizes()]
+        out["buckets_rebuilt"] = bool(getattr(model, "buckets_rebuilt", False))
+    return out
+
+
+def _allreduce_busbw(pg, dist, device, world_size, sizes_mb=(16, 32, 64, 128, 256), iters=10):
     """Bus bandwidth (GB/s, 2(N-1)/N * bytes / time) of bf16 all-reduces of the given sizes."""
     import torch
 

@@ -151,7 +151,7 @@ def build_gpu(force=False, verbose=False, jobs_n=8):
             hipcc, "-shared", f"--offload-arch={GPU_ARCH}", "-fno-gpu-rdc", "-o", out, *objs,
             "-L" + str(tlib), "-Wl,-rpath," + str(tlib), "-Wl,--no-as-needed",
             "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
-            "-l:librccl.so", "-l:libamdhip64.so", "-lpthread",
+            "-l:librccl.so", "-l:libamdhip64.so", "-lpthread", "-ldl",
         ], verbose)
     if verbose or cmds:
         print(f"[build] _C: {len(cmds)} object(s) rebuilt in {time.time() - t0:.1f}s -> {out.name}", flush=True)

@@ -4,6 +4,7 @@
 
 #include "comm/rccl_comm.h"
 #include "reducer/reducer.h"
+#include "trace.h"
 
 namespace py = pybind11;
 using namespace dpa;
@@ -16,6 +17,8 @@ PYBIND11_MODULE(_C, m) {
 
   py::class_<RcclComm, std::shared_ptr<RcclComm>>(m, "RcclComm")
       .def_static("unique_id", []() { return py::bytes(RcclComm::unique_id()); })
+      .def_static("device_bus_id", &RcclComm::device_bus_id, py::arg("device"))
+      .def_static("version", &RcclComm::version)
       .def(py::init([](py::bytes uid, int rank, int world, int device) {
              std::string s = uid;
              py::gil_scoped_release nogil;  // blocks until every rank has joined
@@ -43,7 +46,12 @@ PYBIND11_MODULE(_C, m) {
       .def("group_end", &RcclComm::group_end)
       .def("num_async_ops", &RcclComm::num_async_ops)
       .def("destroy", &RcclComm::destroy, py::call_guard<py::gil_scoped_release>())
-      .def("abort", &RcclComm::abort);
+      .def("abort", &RcclComm::abort)
+      .def("set_debug_sync", &RcclComm::set_debug_sync, py::arg("on"))
+      .def("debug_sync", &RcclComm::debug_sync)
+      .def("comm_stream_idle", &RcclComm::comm_stream_idle)
+      .def("set_timing", &RcclComm::set_timing, py::arg("on"))
+      .def("read_timing", &RcclComm::read_timing, py::call_guard<py::gil_scoped_release>());
 
   py::class_<Transport, std::shared_ptr<Transport>>(m, "Transport")
       .def("native_average", &Transport::native_average)
@@ -67,14 +75,15 @@ PYBIND11_MODULE(_C, m) {
 
   py::class_<Reducer, std::shared_ptr<Reducer>>(m, "Reducer")
       .def(py::init([](std::vector<at::Tensor> params, std::vector<BucketSpec> buckets, std::shared_ptr<Transport> t,
-                       bool gradient_as_bucket_view, bool unpack_to_grads) {
+                       bool gradient_as_bucket_view, bool unpack_to_grads, int64_t max_collective_bytes) {
              ReducerOptions o;
              o.gradient_as_bucket_view = gradient_as_bucket_view;
              o.unpack_to_grads = unpack_to_grads;
+             o.max_collective_bytes = max_collective_bytes;
              return std::make_shared<Reducer>(std::move(params), std::move(buckets), std::move(t), o);
            }),
            py::arg("params"), py::arg("buckets"), py::arg("transport"), py::arg("gradient_as_bucket_view") = true,
-           py::arg("unpack_to_grads") = true)
+           py::arg("unpack_to_grads") = true, py::arg("max_collective_bytes") = 0)
       .def("prepare_for_backward", &Reducer::prepare_for_backward, py::arg("sync") = true)
       .def("armed", &Reducer::armed)
       .def("ready_order", &Reducer::ready_order)
@@ -82,9 +91,18 @@ PYBIND11_MODULE(_C, m) {
       .def("num_backward_syncs", &Reducer::num_backward_syncs)
       .def("num_bucket_launches", &Reducer::num_bucket_launches)
       .def("num_pack_launches", &Reducer::num_pack_launches)
+      .def("num_collectives", &Reducer::num_collectives)
+      .def("launch_positions", &Reducer::launch_positions)
+      .def("slices_per_bucket", &Reducer::slices_per_bucket)
       .def("broadcast_parameters", &Reducer::broadcast_parameters, py::arg("root") = 0,
            py::call_guard<py::gil_scoped_release>())
       .def("detach", &Reducer::detach);
+
+  // Profiler ranges (roctx), shared with the reducer's own ranges.
+  m.def("trace_enable", &trace::enable, py::arg("on"));
+  m.def("trace_enabled", &trace::enabled);
+  m.def("trace_push", [](const std::string& name) { trace::push(name); });
+  m.def("trace_pop", []() { trace::pop(); });
 
   init_ops(m);
 }

@@ -71,19 +71,35 @@ std::string RcclComm::unique_id() {
   return std::string(reinterpret_cast<const char*>(&id), sizeof(id));
 }
 
+std::string RcclComm::device_bus_id(int device) {
+  char buf[64] = {0};
+  DPA_HIP_CHECK(hipDeviceGetPCIBusId(buf, sizeof(buf), device));
+  return std::string(buf);
+}
+
+std::string RcclComm::version() {
+  int v = 0;
+  DPA_NCCL_CHECK(ncclGetVersion(&v));
+  std::ostringstream os;
+  os << v / 10000 << "." << (v / 100) % 100 << "." << v % 100;
+  return os.str();
+}
+
 RcclComm::RcclComm(const std::string& uid, int rank, int world, int device)
     : rank_(rank), world_(world), device_(device) {
   if (uid.size() != sizeof(ncclUniqueId)) throw std::runtime_error("RcclComm: bad unique id size");
   ncclUniqueId id;
   std::memcpy(&id, uid.data(), sizeof(id));
   DPA_HIP_CHECK(hipSetDevice(device_));
-  // The communication stream (and torch's stream pools) must exist BEFORE the communicator
-  // is created.  Measured on MI355X / ROCm 7.0 runtime: a stream created after ncclCommInitRank
-  // that exchanges events with the default stream stalls forever (probe: tools/diag_events.cpp),
-  // while a stream created ahead of it works for any number of in-flight operations.
-  (void)c10::hip::getStreamFromPool(/*isHighPriority=*/false, static_cast<c10::DeviceIndex>(device_));
-  ensure_comm_stream();
   DPA_NCCL_CHECK(ncclCommInitRank(&comm_, world_, id, rank_));
+  // The communication stream is created only now, AFTER the communicator exists, and it is a stream of
+  // our own rather than one from torch's pool (whose streams all come into being at the first use of
+  // the pool, possibly before this communicator).  Measured on MI355X (ROCm 7.0 runtime, RCCL 2.26): a
+  // stream that already existed when ncclCommInitRank ran never returned from its first wait on an
+  // event the compute stream had not reached yet (one-rank group, 4 MiB bucket behind eight queued
+  // matmuls; tools/diag_comm_sizes.py and tools/diag_ddp_step.py reproduce it); with a stream created
+  // afterwards every probe passes.  Waits on already-completed events hid the problem in small tests.
+  ensure_comm_stream();
   barrier_scratch_ = at::zeros({1}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, device_));
 }
 
@@ -110,7 +126,13 @@ void RcclComm::destroy() {
   for (hipEvent_t e : fence_events_)
     if (e) (void)hipEventDestroy(e);
   fence_events_.clear();
-  comm_stream_ = nullptr;  // owned by torch's stream pool
+  for (hipEvent_t e : timing_pool_)
+    if (e) (void)hipEventDestroy(e);
+  timing_pool_.clear();
+  op_spans_.clear();
+  wait_spans_.clear();
+  if (comm_stream_ && owns_comm_stream_) (void)hipStreamDestroy(comm_stream_);
+  comm_stream_ = nullptr;
   barrier_scratch_ = at::Tensor();
 }
 
@@ -200,14 +222,25 @@ void RcclComm::barrier() {
 // slot that nobody waited for has finished.  An event is never re-recorded while a stream may
 // still be waiting on its previous record: every slot owns its own fence and completion event.
 void RcclComm::ensure_comm_stream() {
-  // High-priority stream from torch's pool (non-blocking with respect to the default stream), so
-  // RCCL kernels are scheduled ahead of queued backward kernels.  Taken on first use unless the
-  // caller installed one with set_comm_stream().
-  if (!comm_stream_)
-    comm_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/true, static_cast<c10::DeviceIndex>(device_)).stream();
+  // High-priority stream (non-blocking with respect to the default stream), so RCCL kernels are
+  // scheduled ahead of queued backward kernels.  Created by the constructor right after the
+  // communicator unless the caller installs one with set_comm_stream().
+  if (!comm_stream_) {
+    int least = 0, greatest = 0;
+    DPA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    DPA_HIP_CHECK(hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, greatest));
+    owns_comm_stream_ = true;
+  }
 }
 
-void RcclComm::set_comm_stream(uintptr_t handle) { comm_stream_ = reinterpret_cast<hipStream_t>(handle); }
+void RcclComm::set_comm_stream(uintptr_t handle) {
+  if (comm_stream_ && owns_comm_stream_) {
+    (void)hipStreamSynchronize(comm_stream_);
+    (void)hipStreamDestroy(comm_stream_);
+  }
+  comm_stream_ = reinterpret_cast<hipStream_t>(handle);
+  owns_comm_stream_ = false;
+}
 
 void RcclComm::begin_slot(int slot) {
   if (slot < 0) throw std::runtime_error("RcclComm: negative slot");
@@ -223,6 +256,33 @@ void RcclComm::begin_slot(int slot) {
   if (slot_pending_[s]) DPA_HIP_CHECK(hipEventSynchronize(slot_events_[s]));
 }
 
+hipEvent_t RcclComm::timing_event() {
+  if (timing_used_ >= 16384) {
+    // Nobody read the window: start a new one instead of growing without bound.
+    op_spans_.clear();
+    wait_spans_.clear();
+    timing_used_ = 0;
+  }
+  if (timing_used_ == timing_pool_.size()) {
+    hipEvent_t e;
+    DPA_HIP_CHECK(hipEventCreate(&e));
+    timing_pool_.push_back(e);
+  }
+  return timing_pool_[timing_used_++];
+}
+
+void RcclComm::finish_async(int slot, hipEvent_t done, hipEvent_t t0) {
+  if (t0) {
+    hipEvent_t t1 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(t1, comm_stream_));
+    op_spans_.emplace_back(t0, t1);
+  }
+  DPA_HIP_CHECK(hipEventRecord(done, comm_stream_));
+  slot_pending_[static_cast<size_t>(slot)] = 1;
+  ++n_async_;
+  if (debug_sync_) DPA_HIP_CHECK(hipStreamSynchronize(comm_stream_));
+}
+
 void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
   check_tensor(t);
   DeviceGuard g(device_);
@@ -231,12 +291,15 @@ void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
   // Fence: the bucket was filled by kernels queued on the current stream.
   DPA_HIP_CHECK(hipEventRecord(fence, current_stream(device_)));
   DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence, 0));
+  hipEvent_t t0 = nullptr;
+  if (timing_) {
+    t0 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(t0, comm_stream_));
+  }
   if (t.numel() > 0)
     DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                  static_cast<ncclRedOp_t>(op), comm_, comm_stream_));
-  DPA_HIP_CHECK(hipEventRecord(done, comm_stream_));
-  slot_pending_[static_cast<size_t>(slot)] = 1;
-  ++n_async_;
+  finish_async(slot, done, t0);
 }
 
 void RcclComm::broadcast_async(at::Tensor t, int root, int slot) {
@@ -246,12 +309,15 @@ void RcclComm::broadcast_async(at::Tensor t, int root, int slot) {
   hipEvent_t done = slot_events_[static_cast<size_t>(slot)], fence = fence_events_[static_cast<size_t>(slot)];
   DPA_HIP_CHECK(hipEventRecord(fence, current_stream(device_)));
   DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence, 0));
+  hipEvent_t t0 = nullptr;
+  if (timing_) {
+    t0 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(t0, comm_stream_));
+  }
   if (t.numel() > 0)
     DPA_NCCL_CHECK(ncclBroadcast(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                  root, comm_, comm_stream_));
-  DPA_HIP_CHECK(hipEventRecord(done, comm_stream_));
-  slot_pending_[static_cast<size_t>(slot)] = 1;
-  ++n_async_;
+  finish_async(slot, done, t0);
 }
 
 void RcclComm::wait_slot(int slot) {
@@ -262,7 +328,56 @@ void RcclComm::wait_slot(int slot) {
 }
 
 void RcclComm::wait_all_slots() {
+  DeviceGuard g(device_);
+  hipEvent_t w0 = nullptr;
+  if (timing_) {
+    w0 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(w0, current_stream(device_)));
+  }
   for (size_t i = 0; i < slot_events_.size(); ++i) wait_slot(static_cast<int>(i));
+  if (w0) {
+    hipEvent_t w1 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(w1, current_stream(device_)));
+    wait_spans_.emplace_back(w0, w1);
+  }
+}
+
+void RcclComm::set_timing(bool on) {
+  timing_ = on;
+  if (!on) {
+    op_spans_.clear();
+    wait_spans_.clear();
+    timing_used_ = 0;
+  }
+}
+
+std::vector<double> RcclComm::read_timing() {
+  DeviceGuard g(device_);
+  double busy = 0.0, exposed = 0.0;
+  const double n_ops = static_cast<double>(op_spans_.size());
+  // Blocking waits (hipEventSynchronize), never a polling loop over hipEventQuery.
+  for (auto& sp : op_spans_) {
+    DPA_HIP_CHECK(hipEventSynchronize(sp.second));
+    float ms = 0.f;
+    DPA_HIP_CHECK(hipEventElapsedTime(&ms, sp.first, sp.second));
+    busy += ms;
+  }
+  for (auto& sp : wait_spans_) {
+    DPA_HIP_CHECK(hipEventSynchronize(sp.second));
+    float ms = 0.f;
+    DPA_HIP_CHECK(hipEventElapsedTime(&ms, sp.first, sp.second));
+    exposed += ms;
+  }
+  op_spans_.clear();
+  wait_spans_.clear();
+  timing_used_ = 0;
+  return {busy, exposed, n_ops};
+}
+
+bool RcclComm::comm_stream_idle() {
+  DeviceGuard g(device_);
+  if (!comm_stream_) return true;
+  return hipStreamQuery(comm_stream_) == hipSuccess;
 }
 
 void RcclComm::synchronize_comm_stream() {

@@ -25,6 +25,10 @@ namespace dpa {
 class RcclComm {
  public:
   static std::string unique_id();  // 128 raw bytes from ncclGetUniqueId
+  // PCI bus id ("0000:05:00.0") of HIP device `device`: the identity ranks compare before
+  // ncclCommInitRank so that two ranks bound to one GPU are reported instead of hanging.
+  static std::string device_bus_id(int device);
+  static std::string version();  // "2.26.6"-style RCCL version string
 
   RcclComm(const std::string& uid, int rank, int world, int device);
   ~RcclComm();
@@ -63,10 +67,25 @@ class RcclComm {
   void group_end();
 
   void destroy();  // ncclCommFinalize + ncclCommDestroy; idempotent
-  void abort();    // ncclCommAbort (used on timeout paths)
+  void abort();    // ncclCommAbort: unblocks kernels of a collective a peer never joined (teardown on hang)
 
-  // Timing of the last bucket collectives, for the bus-bandwidth report.
   int64_t num_async_ops() const { return n_async_; }
+
+  // Debug serialisation: every asynchronous collective is followed by a host wait for the
+  // communication stream, so compute and communication never run concurrently.
+  void set_debug_sync(bool on) { debug_sync_ = on; }
+  bool debug_sync() const { return debug_sync_; }
+  // True when nothing is queued on the communication stream (blocking check, no event polling).
+  bool comm_stream_idle();
+
+  // Overlap accounting.  While enabled, every asynchronous collective is bracketed by two
+  // timing events on the communication stream and wait_all_slots() by two on the compute
+  // stream.  read_timing() waits for them and returns {comm_busy_ms, exposed_ms, n_ops} of
+  // the window since the previous read: comm_busy_ms is the summed run time of the
+  // collectives, exposed_ms the time the compute stream spent blocked on them (zero when the
+  // backward pass hides the communication completely).
+  void set_timing(bool on);
+  std::vector<double> read_timing();
 
  private:
   void begin_slot(int slot);
@@ -76,12 +95,21 @@ class RcclComm {
   ncclComm_t comm_ = nullptr;
   int rank_, world_, device_;
   hipStream_t comm_stream_ = nullptr;
+  bool owns_comm_stream_ = false;
   std::vector<hipEvent_t> slot_events_;   // completion of the operation on the comm stream
   std::vector<hipEvent_t> fence_events_;  // "inputs are ready" on the stream that produced them
   std::vector<char> slot_pending_;
   at::Tensor barrier_scratch_;
   int64_t n_async_ = 0;
   bool destroyed_ = false;
+  bool debug_sync_ = false;
+  bool timing_ = false;
+  std::vector<hipEvent_t> timing_pool_;                       // timing-enabled events, reused
+  size_t timing_used_ = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> op_spans_;    // per collective, on the comm stream
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> wait_spans_;  // per wait_all_slots, on the compute stream
+  hipEvent_t timing_event();
+  void finish_async(int slot, hipEvent_t done, hipEvent_t t0);
 };
 
 ncclDataType_t to_nccl_dtype(at::ScalarType t);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads) void scale_inplace_kernel(typename S::T* 
 }
 
 template <typename S>
-__global__ __launch_bounds__(kThreads) void multi_sumsq_kernel(CopyTable t, float* out) {
+__global__ __launch_bounds__(kThreads) void multi_sumsq_kernel(CopyTable t, float* partials) {
   __shared__ float scratch[kThreads / 64];
   const int b = blockIdx.x;
   const int ti = find_tensor(t.block_start, t.n, b);
@@ -102,7 +102,17 @@ __global__ __launch_bounds__(kThreads) void multi_sumsq_kernel(CopyTable t, floa
     }
   }
   acc = block_sum<kThreads / 64>(acc, scratch);
-  if (threadIdx.x == 0) atomicAdd(out, acc);
+  // One partial per workgroup; the final sum walks them in a fixed order (no float atomics, so the
+  // gradient norm is bit-identical from run to run).
+  if (threadIdx.x == 0) partials[b] = acc;
+}
+
+__global__ __launch_bounds__(kThreads) void sum_partials_kernel(const float* partials, int n, float* out) {
+  __shared__ float scratch[kThreads / 64];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += kThreads) acc += partials[i];
+  acc = block_sum<kThreads / 64>(acc, scratch);
+  if (threadIdx.x == 0) out[0] = acc;
 }
 
 __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out) {
@@ -138,14 +148,18 @@ void launch_scale_inplace(void* p, long long n, int dtype, float scale, hipStrea
   });
 }
 
-void launch_sumsq(const CopyTable& t, int dtype, float* out, hipStream_t stream) {
+void launch_sumsq(const CopyTable& t, int dtype, float* partials, hipStream_t stream) {
   if (t.n <= 0) return;
   const int blocks = t.block_start[t.n];
   if (blocks <= 0) return;
   dispatch_dtype(dtype, [&](auto s) {
     using S = decltype(s);
-    hipLaunchKernelGGL((multi_sumsq_kernel<S>), dim3(blocks), dim3(kThreads), 0, stream, t, out);
+    hipLaunchKernelGGL((multi_sumsq_kernel<S>), dim3(blocks), dim3(kThreads), 0, stream, t, partials);
   });
+}
+
+void launch_sum_partials(const float* partials, int n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kThreads), 0, stream, partials, n, out);
 }
 
 void launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, hipStream_t stream) {

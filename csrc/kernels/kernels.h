@@ -52,7 +52,10 @@ void launch_adamw(const AdamWTable& t, int param_dtype, int grad_dtype, const fl
                   const float* grad_scale /*device scalar or nullptr*/, hipStream_t stream);
 // Sum of squares of up to kMaxTensors tensors accumulated into out[0] (fp32, pre-zeroed),
 // and the clip coefficient min(1, max_norm / (sqrt(out[0]) + 1e-6)) written by the finisher.
-void launch_sumsq(const CopyTable& t, int dtype, float* out, hipStream_t stream);
+// Writes one partial sum of squares per workgroup (t.block_start[t.n] of them) to `partials`.
+void launch_sumsq(const CopyTable& t, int dtype, float* partials, hipStream_t stream);
+// out[0] = sum of `n` partials, added up in a fixed order by one workgroup.
+void launch_sum_partials(const float* partials, int n, float* out, hipStream_t stream);
 void launch_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out,
                       hipStream_t stream);
 

@@ -156,24 +156,42 @@ void adamw_step(const std::vector<Tensor>& params, const std::vector<Tensor>& gr
     }
 }
 
+// out[0] = sum of squares over all tensors.  Two stages with a fixed summation order: every
+// workgroup writes its partial into a scratch vector, one workgroup adds the partials up.
 void grad_sumsq(const std::vector<Tensor>& tensors, Tensor out) {
   check_gpu(out, "out");
   TORCH_CHECK(out.scalar_type() == at::kFloat && out.numel() >= 1, "grad_sumsq: float32 accumulator expected");
   if (tensors.empty()) return;
   DevGuard g(out);
   hipStream_t stream = stream_of(out);
+  int64_t total_blocks = 0;
+  for (const Tensor& t : tensors) {
+    check_gpu(t, "tensor");
+    TORCH_CHECK(t.get_device() == out.get_device(), "grad_sumsq: device mismatch");
+    TORCH_CHECK(kdtype(t) >= 0, "grad_sumsq: unsupported dtype");
+    total_blocks += (t.numel() + kernels::CopyTable::kChunk - 1) / kernels::CopyTable::kChunk;
+  }
+  if (total_blocks == 0) {
+    out.zero_();
+    return;
+  }
+  TORCH_CHECK(total_blocks < (1ll << 31), "grad_sumsq: too many elements");
+  Tensor partials = at::empty({total_blocks}, out.options());
+  float* pp = partials.data_ptr<float>();
+  int64_t done = 0;
   for (int dt = 0; dt < 3; ++dt) {
     kernels::CopyTable tab;
     tab.n = 0;
     tab.block_start[0] = 0;
     auto flush = [&]() {
-      if (tab.n > 0) kernels::launch_sumsq(tab, dt, out.data_ptr<float>(), stream);
+      if (tab.n > 0) {
+        kernels::launch_sumsq(tab, dt, pp + done, stream);
+        done += tab.block_start[tab.n];
+      }
       tab.n = 0;
       tab.block_start[0] = 0;
     };
     for (const Tensor& t : tensors) {
-      check_gpu(t, "tensor");
-      TORCH_CHECK(t.get_device() == out.get_device(), "grad_sumsq: device mismatch");
       if (kdtype(t) != dt || t.numel() == 0) continue;
       if (tab.n == kernels::CopyTable::kMaxTensors) flush();
       const int k = tab.n;
@@ -185,6 +203,7 @@ void grad_sumsq(const std::vector<Tensor>& tensors, Tensor out) {
     }
     flush();
   }
+  kernels::launch_sum_partials(pp, static_cast<int>(total_blocks), out.data_ptr<float>(), stream);
 }
 
 void clip_coef(Tensor sumsq, double max_norm, Tensor coef, Tensor norm_out) {

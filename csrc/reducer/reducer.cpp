@@ -5,9 +5,11 @@
 #include <torch/csrc/autograd/utils/lambda_post_hook.h>
 #include <torch/csrc/autograd/variable.h>
 
+#include <algorithm>
 #include <stdexcept>
 
 #include "kernels/kernels.h"
+#include "trace.h"
 
 namespace dpa {
 
@@ -112,6 +114,7 @@ Reducer::Reducer(std::vector<at::Tensor> params, std::vector<BucketSpec> buckets
     : params_(std::move(params)), transport_(std::move(transport)), opt_(options) {
   locator_.assign(params_.size(), {-1, -1});
   buckets_.reserve(buckets.size());
+  int next_slot = 0;
   for (size_t b = 0; b < buckets.size(); ++b) {
     BucketState bs;
     bs.spec = std::move(buckets[b]);
@@ -132,6 +135,19 @@ Reducer::Reducer(std::vector<at::Tensor> params, std::vector<BucketSpec> buckets
     }
     bs.ready.assign(sp.param_indices.size(), 0);
     bs.pending = static_cast<int64_t>(sp.param_indices.size());
+    // Collective slices: whole bucket, or cap-sized pieces whose boundaries stay 128-byte aligned.
+    const int64_t total = sp.buffer.numel();
+    const int64_t esz = static_cast<int64_t>(sp.buffer.element_size());
+    int64_t per = total;
+    if (opt_.max_collective_bytes > 0 && total * esz > opt_.max_collective_bytes) {
+      per = std::max<int64_t>(opt_.max_collective_bytes / esz / 128 * 128, 128);
+    }
+    for (int64_t off = 0; off < total || (total == 0 && off == 0); off += per) {
+      bs.slices.emplace_back(off, std::min(per, total - off));
+      if (total == 0) break;
+    }
+    bs.slot_base = next_slot;
+    next_slot += static_cast<int>(bs.slices.size());
     buckets_.push_back(std::move(bs));
   }
   for (size_t i = 0; i < params_.size(); ++i) {
@@ -161,6 +177,7 @@ void Reducer::prepare_for_backward(bool sync) {
   callback_queued_ = false;
   next_bucket_ = 0;
   ready_order_.clear();
+  launch_pos_.assign(buckets_.size(), -1);
   for (auto& bs : buckets_) {
     bs.pending = static_cast<int64_t>(bs.spec.param_indices.size());
     bs.launched = false;
@@ -194,49 +211,60 @@ void Reducer::launch_ready_buckets() {
   }
 }
 
+std::vector<int64_t> Reducer::slices_per_bucket() const {
+  std::vector<int64_t> out;
+  for (const auto& bs : buckets_) out.push_back(static_cast<int64_t>(bs.slices.size()));
+  return out;
+}
+
+void Reducer::multi_copy(const std::vector<std::pair<at::Tensor, at::Tensor>>& src_dst, float scale) {
+  if (src_dst.empty()) return;
+  at::NoGradGuard ng;
+  auto fast = [](const at::Tensor& t) { return t.is_cuda() && t.is_contiguous() && kernel_dtype(t.scalar_type()) >= 0; };
+  std::vector<size_t> fast_ids;
+  for (size_t i = 0; i < src_dst.size(); ++i) {
+    const at::Tensor& src = src_dst[i].first;
+    at::Tensor dst = src_dst[i].second;
+    if (src.numel() != dst.numel()) throw std::invalid_argument("Reducer: copy between tensors of different size");
+    if (fast(src) && fast(dst) && src.get_device() == dst.get_device()) {
+      fast_ids.push_back(i);
+    } else {
+      dst.copy_(src);
+      if (scale != 1.f) dst.mul_(scale);
+    }
+  }
+  if (fast_ids.empty()) return;
+  hipStream_t stream = current_stream_of(src_dst[fast_ids[0]].second);
+  for (int src_dt = 0; src_dt < 3; ++src_dt)
+    for (int dst_dt = 0; dst_dt < 3; ++dst_dt) {
+      kernels::CopyTable tab;
+      tab.n = 0;
+      tab.block_start[0] = 0;
+      auto flush = [&](kernels::CopyTable& t) {
+        kernels::launch_multi_copy_scale(t, src_dt, dst_dt, scale, stream);
+        ++n_pack_launches_;
+      };
+      for (size_t i : fast_ids) {
+        const at::Tensor& src = src_dst[i].first;
+        const at::Tensor& dst = src_dst[i].second;
+        if (kernel_dtype(src.scalar_type()) != src_dt || kernel_dtype(dst.scalar_type()) != dst_dt) continue;
+        table_add(tab, src.data_ptr(), dst.data_ptr(), src.numel(), flush);
+      }
+      if (tab.n > 0) flush(tab);
+    }
+}
+
 void Reducer::pack_into_bucket(BucketState& bs, const std::vector<int64_t>& local_ids, float scale) {
-  if (local_ids.empty()) return;
-  const at::Tensor& buf = bs.spec.buffer;
-  const int dst_dt = kernel_dtype(buf.scalar_type());
-  bool gpu_fast = buf.is_cuda() && dst_dt >= 0;
-  if (gpu_fast) {
-    for (int64_t j : local_ids) {
-      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
-      if (!g.is_contiguous() || kernel_dtype(g.scalar_type()) < 0 || !g.is_cuda()) gpu_fast = false;
-    }
-  }
-  if (!gpu_fast) {
-    for (int64_t j : local_ids) {
-      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
-      at::Tensor& v = bs.views[static_cast<size_t>(j)];
-      v.copy_(g);
-      if (scale != 1.f) v.mul_(scale);
-    }
-    return;
-  }
-  hipStream_t stream = current_stream_of(buf);
-  // Source dtypes may differ per tensor in principle; group launches by source dtype.
-  for (int src_dt = 0; src_dt < 3; ++src_dt) {
-    kernels::CopyTable tab;
-    tab.n = 0;
-    tab.block_start[0] = 0;
-    auto flush = [&](kernels::CopyTable& t) {
-      kernels::launch_multi_copy_scale(t, src_dt, dst_dt, scale, stream);
-      ++n_pack_launches_;
-    };
-    for (int64_t j : local_ids) {
-      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
-      if (kernel_dtype(g.scalar_type()) != src_dt) continue;
-      table_add(tab, g.data_ptr(), bs.views[static_cast<size_t>(j)].data_ptr(), g.numel(), flush);
-    }
-    if (tab.n > 0) flush(tab);
-  }
+  std::vector<std::pair<at::Tensor, at::Tensor>> pairs;
+  pairs.reserve(local_ids.size());
+  for (int64_t j : local_ids)
+    pairs.emplace_back(params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad(),
+                       bs.views[static_cast<size_t>(j)]);
+  multi_copy(pairs, scale);
 }
 
 void Reducer::unpack_from_bucket(BucketState& bs) {
-  const at::Tensor& buf = bs.spec.buffer;
-  const int src_dt = kernel_dtype(buf.scalar_type());
-  std::vector<int64_t> todo;
+  std::vector<std::pair<at::Tensor, at::Tensor>> pairs;
   for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
     at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
     const at::Tensor& g = p.grad();
@@ -246,58 +274,34 @@ void Reducer::unpack_from_bucket(BucketState& bs) {
       continue;
     }
     if (g.data_ptr() == bs.views[j].data_ptr()) continue;
-    todo.push_back(static_cast<int64_t>(j));
+    pairs.emplace_back(bs.views[j], g);
   }
-  if (todo.empty()) return;
-  bool gpu_fast = buf.is_cuda() && src_dt >= 0;
-  if (gpu_fast)
-    for (int64_t j : todo) {
-      const at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].grad();
-      if (!g.is_contiguous() || kernel_dtype(g.scalar_type()) < 0) gpu_fast = false;
-    }
-  if (!gpu_fast) {
-    for (int64_t j : todo)
-      params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].mutable_grad().copy_(bs.views[static_cast<size_t>(j)]);
-    return;
-  }
-  hipStream_t stream = current_stream_of(buf);
-  for (int dst_dt = 0; dst_dt < 3; ++dst_dt) {
-    kernels::CopyTable tab;
-    tab.n = 0;
-    tab.block_start[0] = 0;
-    auto flush = [&](kernels::CopyTable& t) {
-      kernels::launch_multi_copy_scale(t, src_dt, dst_dt, 1.f, stream);
-      ++n_pack_launches_;
-    };
-    for (int64_t j : todo) {
-      at::Tensor& g = params_[static_cast<size_t>(bs.spec.param_indices[static_cast<size_t>(j)])].mutable_grad();
-      if (kernel_dtype(g.scalar_type()) != dst_dt) continue;
-      table_add(tab, bs.views[static_cast<size_t>(j)].data_ptr(), g.data_ptr(), g.numel(), flush);
-    }
-    if (tab.n > 0) flush(tab);
-  }
+  multi_copy(pairs, 1.f);
 }
 
 void Reducer::launch_bucket(size_t b) {
   BucketState& bs = buckets_[b];
+  trace::Range range(trace::enabled() ? "bucket " + std::to_string(b) + " launch (" +
+                                            std::to_string(bs.spec.buffer.numel() * bs.spec.buffer.element_size()) + " B)"
+                                      : std::string());
   const bool pre_divide = !transport_->native_average() && transport_->world() > 1;
   const float scale = pre_divide ? 1.f / static_cast<float>(transport_->world()) : 1.f;
   std::vector<int64_t> to_copy;
-  bool any_view = false;
   for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
     at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
     const at::Tensor& g = p.grad();
     at::Tensor& v = bs.views[j];
-    if (!bs.ready[j] || !g.defined()) {
-      v.zero_();  // no gradient produced locally: contributes zeros
+    if (!g.defined()) {
+      v.zero_();  // no gradient exists locally: this rank contributes zeros
     } else if (g.data_ptr() == v.data_ptr()) {
-      any_view = true;  // accumulated in place inside the bucket
+      // Accumulated in place inside the bucket (also a gradient kept from earlier no_sync()
+      // micro-steps of a parameter that was not used in this one).
       if (pre_divide) v.mul_(scale);
     } else {
+      // A gradient that lives outside the arena, produced now or accumulated under no_sync().
       to_copy.push_back(static_cast<int64_t>(j));
     }
   }
-  (void)any_view;
   pack_into_bucket(bs, to_copy, scale);
   if (opt_.gradient_as_bucket_view) {
     for (int64_t j : to_copy) {
@@ -305,14 +309,21 @@ void Reducer::launch_bucket(size_t b) {
       if (p.scalar_type() == bs.spec.buffer.scalar_type()) p.mutable_grad() = bs.views[static_cast<size_t>(j)];
     }
   }
-  transport_->all_reduce_async(bs.spec.buffer, static_cast<int>(b), /*average=*/true);
+  for (size_t k = 0; k < bs.slices.size(); ++k) {
+    const auto& sl = bs.slices[k];
+    at::Tensor piece = bs.slices.size() == 1 ? bs.spec.buffer : bs.spec.buffer.narrow(0, sl.first, sl.second);
+    transport_->all_reduce_async(piece, bs.slot_base + static_cast<int>(k), /*average=*/true);
+    ++n_collectives_;
+  }
   bs.launched = true;
+  launch_pos_[b] = static_cast<int64_t>(ready_order_.size());
   ++n_launches_;
 }
 
 void Reducer::finalize_backward() {
   std::lock_guard<std::mutex> g(mu_);
   if (!armed_) return;
+  trace::Range range("reducer finalize");
   // Buckets that never filled up (parameters without a gradient this iteration) go out now,
   // still in index order, so the collective sequence is identical on every rank.
   for (size_t b = next_bucket_; b < buckets_.size(); ++b) launch_bucket(b);
@@ -323,24 +334,34 @@ void Reducer::finalize_backward() {
   armed_ = false;
   callback_queued_ = false;
   last_ready_order_ = ready_order_;
+  last_launch_pos_ = launch_pos_;
   ++n_syncs_;
 }
 
 void Reducer::broadcast_parameters(int root) {
-  // Parameters are sent bucket by bucket through the (already allocated) gradient buffers:
-  // pack -> broadcast -> unpack, so no second flat copy of the model is needed.
+  // Parameters travel bucket by bucket through the (already allocated) gradient buffers:
+  // one multi-tensor pack launch, one broadcast, one unpack launch per bucket, so no second
+  // flat copy of the model is needed.
+  at::NoGradGuard ng;
   for (auto& bs : buckets_) {
-    for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
-      const at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
-      at::NoGradGuard ng;
-      bs.views[j].copy_(p.detach());
-    }
-    transport_->broadcast(bs.spec.buffer, root);
+    std::vector<std::pair<at::Tensor, at::Tensor>> in, out;
     for (size_t j = 0; j < bs.spec.param_indices.size(); ++j) {
       at::Tensor p = params_[static_cast<size_t>(bs.spec.param_indices[j])].detach();
-      at::NoGradGuard ng;
-      p.copy_(bs.views[j]);
+      // A bucket narrower than its parameters (bf16 buckets under fp32 parameters) would round
+      // the weights on the way: such tensors are broadcast on their own.
+      if (p.element_size() > bs.spec.buffer.element_size()) {
+        at::Tensor flat = p.is_contiguous() ? p : p.contiguous();
+        transport_->broadcast(flat.view({-1}), root);
+        if (!p.is_contiguous()) p.copy_(flat);
+        continue;
+      }
+      in.emplace_back(p, bs.views[j]);
+      out.emplace_back(bs.views[j], p);
     }
+    if (in.empty()) continue;
+    multi_copy(in, 1.f);
+    transport_->broadcast(bs.spec.buffer, root);
+    multi_copy(out, 1.f);
     bs.spec.buffer.zero_();
   }
 }

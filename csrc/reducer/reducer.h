@@ -56,6 +56,11 @@ struct BucketSpec {
 struct ReducerOptions {
   bool gradient_as_bucket_view = true;
   bool unpack_to_grads = true;  // when .grad is not a view: copy reduced values back into .grad
+  // A bucket larger than this goes out as several all-reduces over consecutive slices of its
+  // flat buffer (0 = one collective per bucket).  Keeps a single huge tensor (an embedding
+  // table, an 8192x8192 layer) from being one monolithic operation: each slice has its own
+  // completion event, and on the host-side (gloo) transport the slices run concurrently.
+  int64_t max_collective_bytes = 0;
 };
 
 class Reducer {
@@ -75,6 +80,12 @@ class Reducer {
   int64_t num_backward_syncs() const { return n_syncs_; }
   int64_t num_bucket_launches() const { return n_launches_; }
   int64_t num_pack_launches() const { return n_pack_launches_; }
+  int64_t num_collectives() const { return n_collectives_; }
+  // Per bucket: how many gradients had been reported ready when it was launched in the last
+  // synced backward (a bucket laid out in ready order launches exactly when its last tensor arrives).
+  std::vector<int64_t> launch_positions() const { return last_launch_pos_; }
+  // Per bucket: number of all-reduce slices.
+  std::vector<int64_t> slices_per_bucket() const;
   // Broadcast every bucket-ordered parameter from `root` (initial parameter sync).
   void broadcast_parameters(int root);
   // Removes the autograd hooks (also done by the destructor).
@@ -87,6 +98,8 @@ class Reducer {
     int64_t pending = 0;
     bool launched = false;
     std::vector<char> ready;            // per tensor in the bucket
+    std::vector<std::pair<int64_t, int64_t>> slices;  // (element offset, numel) per collective
+    int slot_base = 0;                  // first completion slot of this bucket
   };
 
   void autograd_hook(int64_t param_index);
@@ -95,6 +108,9 @@ class Reducer {
   void finalize_backward();
   void pack_into_bucket(BucketState& bs, const std::vector<int64_t>& local_ids, float scale);
   void unpack_from_bucket(BucketState& bs);
+  // dst[i] = cast(src[i] * scale) for every pair; dense GPU tensors of one (src, dst) dtype
+  // combination share one multi-tensor launch, anything else falls back to copy_().
+  void multi_copy(const std::vector<std::pair<at::Tensor, at::Tensor>>& src_dst, float scale);
 
   std::vector<at::Tensor> params_;
   std::vector<BucketState> buckets_;
@@ -108,7 +124,8 @@ class Reducer {
   bool callback_queued_ = false;
   size_t next_bucket_ = 0;
   std::vector<int64_t> ready_order_, last_ready_order_;
-  int64_t n_syncs_ = 0, n_launches_ = 0, n_pack_launches_ = 0;
+  std::vector<int64_t> launch_pos_, last_launch_pos_;
+  int64_t n_syncs_ = 0, n_launches_ = 0, n_pack_launches_ = 0, n_collectives_ = 0;
 };
 
 }  // namespace dpa

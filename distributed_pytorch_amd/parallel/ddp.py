@@ -28,6 +28,10 @@ _REDUCE_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch
                   "fp16": torch.float16, "float16": torch.float16}
 _IGNORED_KWARGS = ("output_device", "dim", "check_reduction", "static_graph", "delay_all_reduce_named_params",
                    "param_to_hook_all_reduce", "mixed_precision", "device_mesh", "skip_all_reduce_unused_params")
+# Positional order of torch's DistributedDataParallel after (module, device_ids): the reference forwards
+# ``*args`` to it untouched (reference distributed.py:112-114), so the same call must bind the same way here.
+_TORCH_POSITIONAL = ("output_device", "dim", "broadcast_buffers", "init_sync", "process_group", "bucket_cap_mb",
+                     "find_unused_parameters", "check_reduction", "gradient_as_bucket_view", "static_graph")
 
 
 def _mb_env(name: str, default_mb: float) -> int:
@@ -47,12 +51,34 @@ def default_first_bucket_bytes() -> int:
     return _mb_env("DIST_FIRST_BUCKET_MB", 4)
 
 
+def default_max_collective_bytes(bucket_bytes: int) -> int:
+    """Largest single all-reduce: a tensor bigger than the bucket cap (a tied embedding table,
+    an 8192x8192 layer) closes its bucket far above the cap and is sent as cap-sized slices."""
+    v = os.environ.get("DIST_MAX_COLLECTIVE_MB")
+    return int(float(v) * (1 << 20)) if v not in (None, "") else int(bucket_bytes)
+
+
 class DistributedDataParallel(nn.Module):
-    def __init__(self, module: nn.Module, device_ids=None, *, bucket_cap_mb: Optional[float] = None,
+    def __init__(self, module: nn.Module, device_ids=None, *args, bucket_cap_mb: Optional[float] = None,
                  first_bucket_mb: Optional[float] = None, broadcast_buffers: bool = True,
                  find_unused_parameters: bool = False, gradient_as_bucket_view: bool = True,
-                 reduce_dtype=None, init_sync: bool = True, process_group=None, transport=None, **kwargs):
+                 reduce_dtype=None, init_sync: bool = True, process_group=None, transport=None,
+                 rebuild_buckets: Optional[bool] = None, max_collective_mb: Optional[float] = None, **kwargs):
         super().__init__()
+        if len(args) > len(_TORCH_POSITIONAL):
+            raise TypeError(f"DistributedDataParallel: at most {len(_TORCH_POSITIONAL) + 2} positional arguments")
+        if args:
+            given = dict(zip(_TORCH_POSITIONAL, args))
+            clash = [k for k in given if k in kwargs]
+            if clash:
+                raise TypeError(f"DistributedDataParallel: got multiple values for argument(s) {clash}")
+            broadcast_buffers = given.pop("broadcast_buffers", broadcast_buffers)
+            init_sync = given.pop("init_sync", init_sync)
+            process_group = given.pop("process_group", process_group)
+            bucket_cap_mb = given.pop("bucket_cap_mb", bucket_cap_mb)
+            find_unused_parameters = given.pop("find_unused_parameters", find_unused_parameters)
+            gradient_as_bucket_view = given.pop("gradient_as_bucket_view", gradient_as_bucket_view)
+            kwargs.update(given)  # output_device, dim, check_reduction, static_graph: accepted, no effect here
         for k in list(kwargs):
             if k in _IGNORED_KWARGS:
                 kwargs.pop(k)
@@ -97,11 +123,20 @@ class DistributedDataParallel(nn.Module):
         self.reduce_dtype = reduce_dtype
 
         self._verify_replicas()
-        self._build_buckets(
-            int(bucket_cap_mb * (1 << 20)) if bucket_cap_mb is not None else default_bucket_bytes(),
-            int(first_bucket_mb * (1 << 20)) if first_bucket_mb is not None else default_first_bucket_bytes(),
-            gradient_as_bucket_view,
-        )
+        self._bucket_bytes = int(bucket_cap_mb * (1 << 20)) if bucket_cap_mb is not None else default_bucket_bytes()
+        self._first_bucket_bytes = int(first_bucket_mb * (1 << 20)) if first_bucket_mb is not None else default_first_bucket_bytes()
+        self._max_collective_bytes = (int(max_collective_mb * (1 << 20)) if max_collective_mb is not None
+                                      else default_max_collective_bytes(self._bucket_bytes))
+        self._grad_as_view = bool(gradient_as_bucket_view)
+        if rebuild_buckets is None:
+            rebuild_buckets = os.environ.get("DIST_REBUILD_BUCKETS", "1") != "0"
+        # Like torch's reducer, the bucket layout is re-planned once, after the first synchronised
+        # backward pass, from the order in which gradients really became ready.
+        self._rebuild_pending = bool(rebuild_buckets)
+        self.buckets_rebuilt = False
+        self._carried_syncs = 0      # counters of reducers retired by a rebuild
+        self._carried_launches = 0
+        self._build_buckets(None)
         self._flatten_buffers()
         if init_sync and self.world_size > 1:
             self._reducer.broadcast_parameters(0)
@@ -126,7 +161,7 @@ class DistributedDataParallel(nn.Module):
             return self.reduce_dtype
         return p.dtype
 
-    def _build_buckets(self, bucket_bytes: int, first_bucket_bytes: int, grad_as_view: bool) -> None:
+    def _param_metas(self):
         h = _ext.host()
         dtypes: List[torch.dtype] = []
         metas = []
@@ -135,7 +170,15 @@ class DistributedDataParallel(nn.Module):
             if bd not in dtypes:
                 dtypes.append(bd)
             metas.append(h.ParamMeta(p.numel(), torch.empty((), dtype=bd).element_size(), dtypes.index(bd), True))
-        plan = h.plan_buckets(metas, h.PlanOptions(first_bucket_bytes, bucket_bytes, 128, True))
+        return metas, dtypes
+
+    def _build_buckets(self, ready_order: Optional[List[int]]) -> None:
+        """Plans the buckets (registration order reversed, or ``ready_order`` when given), allocates one
+        flat arena per bucket dtype and creates the reducer over slices of it."""
+        h = _ext.host()
+        metas, dtypes = self._param_metas()
+        opts = h.PlanOptions(self._first_bucket_bytes, self._bucket_bytes, 128, True)
+        plan = h.plan_buckets(metas, opts) if ready_order is None else h.plan_buckets_from_order(metas, list(ready_order), opts)
         self._plan = plan
         self._arenas: Dict[int, torch.Tensor] = {
             key: torch.zeros(numel, dtype=dtypes[key], device=self.device) for key, numel in plan.arena_numel
@@ -145,7 +188,57 @@ class DistributedDataParallel(nn.Module):
             buf = self._arenas[b.group_key].narrow(0, b.arena_offset, b.numel)
             specs.append(self._C.BucketSpec(list(b.param_indices), list(b.offsets), buf))
         self._bucket_buffers = [s.buffer for s in specs]
-        self._reducer = self._C.Reducer(self._params, specs, self._transport, bool(grad_as_view), True)
+        self._bucket_params = [list(b.param_indices) for b in plan.buckets]
+        self._reducer = self._C.Reducer(self._params, specs, self._transport, self._grad_as_view, True,
+                                        int(self._max_collective_bytes))
+
+    def _agreed_ready_order(self) -> List[int]:
+        """Rank 0's observed gradient-ready order, on every rank (the layouts must be identical)."""
+        order = [int(i) for i in self._reducer.ready_order()]
+        if self.world_size == 1:
+            return order
+        n = len(self._params)
+        t = torch.full((n + 1,), -1, dtype=torch.int64)
+        t[0] = len(order)
+        t[1:1 + len(order)] = torch.tensor(order, dtype=torch.int64)
+        if pg.is_initialized():
+            pg.broadcast(t, 0)
+        elif tdist.is_initialized():
+            tdist.broadcast(t, 0)
+        k = int(t[0])
+        return [int(i) for i in t[1:1 + k]]
+
+    def rebuild_buckets(self, ready_order: Optional[List[int]] = None) -> bool:
+        """Re-plans the buckets so that bucket k holds the k-th group of gradients to become ready, re-homes
+        the arenas and moves existing ``.grad`` tensors into their new slices.  Returns False when the layout
+        was already the one the order asks for.  Collective on all ranks (the order is rank 0's)."""
+        order = self._agreed_ready_order() if ready_order is None else [int(i) for i in ready_order]
+        h = _ext.host()
+        metas, dtypes = self._param_metas()
+        probe = h.plan_buckets_from_order(metas, order, h.PlanOptions(self._first_bucket_bytes, self._bucket_bytes, 128, True))
+        if [list(b.param_indices) for b in probe.buckets] == self._bucket_params:
+            return False
+        old_reducer, old_arenas = self._reducer, self._arenas
+        old_reducer.detach()
+        self._carried_syncs += int(old_reducer.num_backward_syncs())
+        self._carried_launches += int(old_reducer.num_bucket_launches())
+        self._build_buckets(order)
+        if self._grad_as_view:
+            # Gradients that were views of the old arenas move into the new ones.
+            loc = {pi: (b, j) for b, idxs in enumerate(self._bucket_params) for j, pi in enumerate(idxs)}
+            with torch.no_grad():
+                for pi, p in enumerate(self._params):
+                    g = p.grad
+                    if g is None or g.dtype != self._bucket_dtype(p):
+                        continue
+                    b, j = loc[pi]
+                    off = self._plan.buckets[b].offsets[j]
+                    v = self._bucket_buffers[b].narrow(0, off, p.numel()).view(p.shape)
+                    v.copy_(g)
+                    p.grad = v
+        del old_reducer, old_arenas
+        self.buckets_rebuilt = True
+        return True
 
     def _flatten_buffers(self) -> None:
         """Re-homes module buffers into one flat tensor per dtype so that keeping them in
@@ -179,6 +272,11 @@ class DistributedDataParallel(nn.Module):
     # ------------------------------------------------------------------ nn.Module surface
     def forward(self, *inputs, **kwargs):
         if torch.is_grad_enabled():
+            if self._rebuild_pending and self.require_backward_grad_sync and self._reducer.num_backward_syncs() >= 1:
+                self._rebuild_pending = False
+                self.rebuild_buckets()
+            if self.require_backward_grad_sync:
+                pg.progress_tick()  # one entered "collective" per synchronised backward pass
             self._reducer.prepare_for_backward(self.require_backward_grad_sync)
             if self.broadcast_buffers and self._buffer_arenas and self.require_backward_grad_sync:
                 with torch.no_grad():
@@ -200,6 +298,13 @@ class DistributedDataParallel(nn.Module):
     @property
     def reducer(self):
         return self._reducer
+
+    def num_backward_syncs(self) -> int:
+        """Synchronised backward passes since construction (across bucket rebuilds)."""
+        return self._carried_syncs + int(self._reducer.num_backward_syncs())
+
+    def num_bucket_launches(self) -> int:
+        return self._carried_launches + int(self._reducer.num_bucket_launches())
 
     def bucket_sizes(self) -> List[int]:
         return [int(b.numel() * b.element_size()) for b in self._bucket_buffers]

@@ -54,6 +54,16 @@ class ProcessExitedException(RuntimeError):
         self.signal_name = signal_name
 
 
+class ProcessHungException(RuntimeError):
+    """The hang monitor ended the job: ``ranks`` stayed behind their peers (see ``heartbeat.py``)."""
+
+    def __init__(self, msg: str, ranks: List[int], counters: Dict[int, int]):
+        super().__init__(msg)
+        self.ranks = ranks
+        self.rank = ranks[0] if ranks else -1
+        self.counters = counters
+
+
 # --------------------------------------------------------------------------- device list
 def visible_device_ids(device_count: int) -> Optional[List[str]]:
     """IDs the user pinned through a visibility variable, or ``None`` if none is set.
@@ -233,7 +243,7 @@ class ProcessContext:
         raise ProcessExitedException(f"process {failed} terminated with exit code {code}", failed, p.pid, code)
 
 
-def spawn(worker_fn: Callable, args: tuple = (), nprocs: int = 1, *, env_per_rank: Optional[List[Dict[str, Optional[str]]]] = None, pin_cpus: bool = True, join: bool = True):
+def spawn(worker_fn: Callable, args: tuple = (), nprocs: int = 1, *, env_per_rank: Optional[List[Dict[str, Optional[str]]]] = None, pin_cpus: bool = True, join: bool = True, monitor=None):
     """Start ``nprocs`` fresh interpreters running ``worker_fn(rank, *args)``.
 
     ``worker_fn`` must be importable from the child (module-level function) and the
@@ -279,8 +289,21 @@ def spawn(worker_fn: Callable, args: tuple = (), nprocs: int = 1, *, env_per_ran
         for s in (signal.SIGINT, signal.SIGTERM):
             old_handlers[s] = signal.signal(s, _forward)
     try:
-        while not pc.join():
-            pass
+        watching = monitor is not None and monitor.enabled
+        while not pc.join(timeout=1.0 if watching else None):
+            if not watching:
+                continue
+            verdict = monitor.poll()
+            if verdict is not None:
+                msg = verdict.message()
+                sys.stderr.write(f"[launcher] hang detected: {msg}; terminating all {nprocs} workers\n")
+                sys.stderr.flush()
+                monitor.post_abort(verdict)  # ranks abort their communicators and exit by themselves ...
+                deadline = time.time() + 5.0
+                while time.time() < deadline and any(p.is_alive() for p in procs):
+                    time.sleep(0.1)
+                pc.terminate_all()           # ... whoever is still there is signalled
+                raise ProcessHungException(msg, verdict.ranks, verdict.counters)
     except BaseException:
         pc.terminate_all()
         raise
@@ -329,10 +352,15 @@ def launch(worker_fn: Callable, *args, nprocs: Optional[int] = None):
                     env_per_rank[r].update(child_device_env(ids[:world_size], r, mode))
         store = Store("127.0.0.1", 0, is_host=True, bind_addr="127.0.0.1")
         try:
-            common = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(store.port), "DIST_STORE_HOSTED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+            # Nothing that changes how the runtime opens peer / IPC mappings is set here: variables such as
+            # HSA_ENABLE_IPC_MODE_LEGACY reach the workers exactly as the caller exported them.
+            common = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(store.port), "DIST_STORE_HOSTED": "1"}
             for e in env_per_rank:
                 e.update(common)
-            spawn(worker_fn, args=(world_size, *args), nprocs=world_size, env_per_rank=env_per_rank, pin_cpus=os.environ.get("DIST_CPU_AFFINITY", "1") != "0", join=True)
+            from .heartbeat import HangMonitor
+
+            spawn(worker_fn, args=(world_size, *args), nprocs=world_size, env_per_rank=env_per_rank, pin_cpus=os.environ.get("DIST_CPU_AFFINITY", "1") != "0", join=True,
+                  monitor=HangMonitor(store, world_size))
         finally:
             store.close()
     elif world_size == 1:

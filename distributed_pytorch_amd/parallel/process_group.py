@@ -16,13 +16,18 @@ from __future__ import annotations
 
 import datetime
 import os
+import signal
+import socket
+import sys
+import threading
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as tdist
 
 from .. import _ext
+from . import heartbeat as hb
 from .store import Store, TorchStoreAdapter, create_store_from_env
 
 # ncclRedOp_t values
@@ -41,6 +46,10 @@ class _State:
     owns_c10d: bool = False
     timeout_s: float = 300.0
     gen: int = 0
+    heartbeat: Optional[hb.Heartbeat] = None
+    monitor_stop: Optional[threading.Event] = None
+    monitor_store: Optional[Store] = None
+    old_sigterm: object = None
 
 
 _state: Optional[_State] = None
@@ -121,6 +130,61 @@ def get_device() -> torch.device:
     return torch.device("cpu")
 
 
+def progress_tick() -> None:
+    """Counts one entered collective for the hang monitor (see ``heartbeat.py``)."""
+    st = _state
+    if st is not None and st.heartbeat is not None:
+        st.heartbeat.count += 1
+
+
+# ------------------------------------------------------------------------------ device map
+def check_device_map(entries: Sequence[Tuple[int, str, str]]) -> Optional[str]:
+    """``entries`` are (rank, host, PCI bus id).  Returns the error text when two ranks of one
+    host are bound to the same GPU (RCCL would refuse or hang in ``ncclCommInitRank``), else None."""
+    seen = {}
+    for rank, host, bus in entries:
+        key = (host, bus.lower())
+        if key in seen:
+            return (f"ranks {seen[key]} and {rank} are both bound to GPU {bus} on {host}: every rank needs its own "
+                    f"device (check HIP_VISIBLE_DEVICES / LOCAL_RANK / DIST_GPU_BINDING)")
+        seen[key] = rank
+    return None
+
+
+def format_device_map(entries: Sequence[Tuple[int, str, str]], extra: str = "") -> str:
+    rows = ", ".join(f"{r}->{bus}" for r, _h, bus in sorted(entries))
+    return f"[rccl] rank->GPU (PCI bus id): {rows}{extra}"
+
+
+def _verify_devices(C, st: Store, state: "_State", dev: torch.device) -> None:
+    """Every rank publishes the PCI bus id of its device; rank 0 checks that they are pairwise
+    distinct *before* the communicator is created and prints the map plus the transport-relevant
+    environment, so a first multi-GPU run that goes wrong says why."""
+    gen, rank, world = state.gen, state.rank, state.world_size
+    bus = C.RcclComm.device_bus_id(dev.index if dev.index is not None else 0)
+    st.set(f"rccl/dev/{gen}/{rank}", f"{socket.gethostname()}|{bus}")
+    verdict_key = f"rccl/devcheck/{gen}"
+    if rank == 0:
+        entries = []
+        for r in range(world):
+            host, b = st.get(f"rccl/dev/{gen}/{r}", state.timeout_s).decode().split("|", 1)
+            entries.append((r, host, b))
+        err = check_device_map(entries)
+        st.set(verdict_key, err or "ok")
+        if world > 1 and os.environ.get("DIST_QUIET_INIT", "0") != "1":
+            env = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_P2P_DISABLE",
+                                                  "NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS")}
+            shown = " ".join(f"{k}={v}" for k, v in env.items() if v is not None)
+            sys.stderr.write(format_device_map(entries, f" | rccl {C.RcclComm.version()} | {shown or 'no transport overrides'}") + "\n")
+            if env["NCCL_P2P_DISABLE"] not in (None, "0"):
+                sys.stderr.write("[rccl] warning: NCCL_P2P_DISABLE is set -- collectives will bounce through host memory "
+                                 "instead of xGMI\n")
+            sys.stderr.flush()
+    verdict = st.get(verdict_key, state.timeout_s).decode()
+    if verdict != "ok":
+        raise RuntimeError(f"init_process_group: {verdict}")
+
+
 # ------------------------------------------------------------------------------ lifecycle
 def init_process_group(rank: int, world_size: int, backend: Optional[str] = None, *, timeout_s: Optional[float] = None, store: Optional[Store] = None) -> None:
     global _state
@@ -152,12 +216,14 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
         dev = torch.device(f"cuda:{local_device_index(rank)}")
         torch.cuda.set_device(dev)  # explicit binding; the reference leaves this to NCCL's inference
         state.device = dev
+        _verify_devices(C, st, state, dev)
         key = f"rccl/uid/{gen}"
         if rank == 0:
             st.set(key, C.RcclComm.unique_id())
         uid = st.get(key, timeout_s)
         # Communicator is created eagerly so that iteration 0 does not pay for it.
         state.comm = C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0)
+        state.comm.set_debug_sync(debug_sync())
     else:
         state.device = torch.device("cpu") if not torch.cuda.is_available() else torch.device(f"cuda:{local_device_index(rank)}")
         if not tdist.is_initialized():
@@ -169,6 +235,54 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
     _state = state
     # Everyone has joined before anyone proceeds; also surfaces a dead rank at start-up.
     st.barrier(f"init/{gen}", world_size, timeout_s)
+    if world_size > 1:
+        _start_hang_detection(state)
+
+
+def _start_hang_detection(state: "_State") -> None:
+    """Heartbeat publisher on every rank; the monitor runs in the launcher parent when it hosts
+    the store, otherwise (``torch.distributed.run``, hand-exported MASTER_*) on the hosting rank."""
+    st = state.store
+    enabled = hb.hang_timeout_s() > 0 or hb.stall_timeout_s() > 0
+    if enabled:
+        state.heartbeat = hb.Heartbeat(st.host, st.port, state.rank, on_abort=lambda _reason: abort())
+    if enabled and st.is_host:
+        state.monitor_store = Store(st.host, st.port, is_host=False, timeout=10.0)
+        mon = hb.HangMonitor(state.monitor_store, state.world_size)
+
+        def on_hang(v):
+            sys.stderr.write(f"[hang monitor] {v.message()}; terminating the job\n")
+            sys.stderr.flush()
+            abort()
+            os._exit(hb.EXIT_CODE_ABORTED)
+
+        state.monitor_stop = mon.watch_in_thread(on_hang)
+    if state.comm is not None and threading.current_thread() is threading.main_thread():
+        # SIGTERM (launcher teardown) aborts the communicator first, so kernels of a collective
+        # that a peer never joined are released before the process goes away.
+        def _on_term(signum, frame):
+            abort()
+            prev = state.old_sigterm
+            if callable(prev):
+                prev(signum, frame)
+            else:
+                signal.signal(signal.SIGTERM, signal.SIG_DFL)
+                os.kill(os.getpid(), signal.SIGTERM)
+
+        try:
+            state.old_sigterm = signal.signal(signal.SIGTERM, _on_term)
+        except ValueError:
+            state.old_sigterm = None
+
+
+def abort() -> None:
+    """``ncclCommAbort`` on the rank's communicator (no-op on gloo / without a group)."""
+    st = _state
+    if st is not None and st.comm is not None:
+        try:
+            st.comm.abort()
+        except Exception:
+            pass
 
 
 def destroy_process_group() -> None:
@@ -178,6 +292,15 @@ def destroy_process_group() -> None:
         return
     _state = None
     try:
+        if st.monitor_stop is not None:
+            st.monitor_stop.set()
+        if st.heartbeat is not None:
+            st.heartbeat.close()
+        if st.old_sigterm is not None:
+            try:
+                signal.signal(signal.SIGTERM, st.old_sigterm)
+            except ValueError:
+                pass
         if st.comm is not None:
             st.comm.destroy()
         if st.owns_c10d and tdist.is_initialized():
@@ -196,6 +319,8 @@ def destroy_process_group() -> None:
                         time.sleep(0.005)
             except Exception:
                 pass
+            if st.monitor_store is not None:
+                st.monitor_store.close()
             st.store.close()
 
 
@@ -221,6 +346,7 @@ def all_reduce(t: torch.Tensor, op=OP_SUM) -> torch.Tensor:
     code = _to_op_code(op)
     if _state is None or _state.world_size == 1:
         return t
+    progress_tick()
     if _state.backend == "rccl":
         s, cpu = _stage_for_rccl(t)
         _state.comm.all_reduce(s, code)
@@ -238,6 +364,7 @@ def reduce(t: torch.Tensor, dst: int = 0, op=OP_SUM) -> torch.Tensor:
     code = _to_op_code(op)
     if _state is None or _state.world_size == 1:
         return t
+    progress_tick()
     if _state.backend == "rccl":
         s, cpu = _stage_for_rccl(t)
         _state.comm.reduce(s, int(dst), code)
@@ -250,6 +377,7 @@ def reduce(t: torch.Tensor, dst: int = 0, op=OP_SUM) -> torch.Tensor:
 def broadcast(t: torch.Tensor, src: int = 0) -> torch.Tensor:
     if _state is None or _state.world_size == 1:
         return t
+    progress_tick()
     if _state.backend == "rccl":
         s, cpu = _stage_for_rccl(t)
         _state.comm.broadcast(s, int(src))
@@ -265,6 +393,7 @@ def gather(t: torch.Tensor, dst: int = 0) -> List[torch.Tensor]:
     if _state is None or _state.world_size == 1:
         return [t]
     w = _state.world_size
+    progress_tick()
     if _state.backend == "rccl":
         s, cpu = _stage_for_rccl(t)
         # One contiguous [world, ...] slab filled by a single ncclGather; rows are returned as views.
@@ -287,6 +416,7 @@ def all_gather(t: torch.Tensor) -> List[torch.Tensor]:
     if _state is None or _state.world_size == 1:
         return [t]
     w = _state.world_size
+    progress_tick()
     if _state.backend == "rccl":
         s, cpu = _stage_for_rccl(t)
         out = torch.empty((w,) + tuple(s.shape), dtype=s.dtype, device=s.device)
@@ -302,6 +432,7 @@ def all_gather(t: torch.Tensor) -> List[torch.Tensor]:
 def barrier() -> None:
     if _state is None or _state.world_size == 1:
         return
+    progress_tick()
     if _state.backend == "rccl":
         _state.comm.barrier()
     else:

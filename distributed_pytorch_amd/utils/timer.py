@@ -50,21 +50,40 @@ class StepTimer:
         return samples_per_step / (self.ms_per_step() * 1e-3)
 
 
+_trace_backend = None  # (push, pop) once resolved
+
+
+def _resolve_trace():
+    """The extension's roctx hooks (the ones the reducer's own bucket ranges go through), or torch's."""
+    global _trace_backend
+    if _trace_backend is not None:
+        return _trace_backend
+    try:
+        from .. import _ext
+
+        C = _ext.C()
+        if C.trace_enable(True):
+            _trace_backend = (C.trace_push, C.trace_pop)
+            return _trace_backend
+    except Exception:
+        pass
+    if torch.cuda.is_available():
+        _trace_backend = (torch.cuda.nvtx.range_push, torch.cuda.nvtx.range_pop)
+    else:
+        _trace_backend = (lambda _n: None, lambda: None)
+    return _trace_backend
+
+
 @contextlib.contextmanager
 def range(name: str):  # noqa: A001 - deliberate: mirrors torch.cuda.nvtx.range
-    """roctx range when a GPU is present, no-op otherwise."""
-    pushed = False
-    if torch.cuda.is_available():
-        try:
-            torch.cuda.nvtx.range_push(name)
-            pushed = True
-        except Exception:
-            pushed = False
+    """Profiler range around a phase of the step (forward / backward / optimizer); shows up in
+    ``rocprofv3 --marker-trace`` together with the reducer's per-bucket launch ranges."""
+    push, pop = _resolve_trace()
+    push(name)
     try:
         yield
     finally:
-        if pushed:
-            torch.cuda.nvtx.range_pop()
+        pop()
 
 
 def allreduce_bus_bandwidth_gbps(nbytes: int, seconds: float, world_size: int) -> float:

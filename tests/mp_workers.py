@@ -107,7 +107,7 @@ def ddp_vs_torch_worker(rank, world_size, out_dir):
     ours(x).sum().backward()
     res["no_sync_local_grad"] = g_local.tolist()
     res["no_sync_final_grad"] = ours.module.c.bias.grad.tolist()
-    res["syncs"] = ours.reducer.num_backward_syncs()
+    res["syncs"] = ours.num_backward_syncs()
     res["unused_grad_is_zero"] = bool(ours.module.unused.weight.grad is None or float(ours.module.unused.weight.grad.abs().sum()) == 0.0)
     _dump(out_dir, rank, res)
     dist.cleanup()
@@ -157,4 +157,90 @@ def checkpoint_worker(rank, world_size, out_dir):
     same = all(torch.equal(before[k], v) for k, v in model.state_dict().items())
     _dump(out_dir, rank, {"restored": same, "step": meta["step"], "note": meta["extra"]["note"],
                           "keys": list(before.keys())})
+    dist.cleanup()
+
+
+class _ScrambledNet(nn.Module):
+    """Layers registered in an order unrelated to the order they run in, so gradients do not
+    become ready in reverse registration order."""
+
+    def __init__(self):
+        super().__init__()
+        self.last = nn.Linear(16, 3)
+        self.first = nn.Linear(6, 16)
+        self.big = nn.Linear(16, 64)     # closes its bucket far above the cap -> sliced all-reduce
+        self.mid = nn.Linear(64, 16)
+        self.skipped = nn.Linear(16, 16)  # used only when asked
+
+    def forward(self, x, use_skipped=True):
+        h = torch.relu(self.first(x))
+        if use_skipped:
+            h = h + self.skipped(h)
+        return self.last(torch.relu(self.mid(torch.relu(self.big(h)))))
+
+
+def ddp_rebuild_worker(rank, world_size, out_dir):
+    """Bucket re-planning from the observed ready order, sliced collectives, positional wrapper
+    arguments and gradients kept across no_sync() for a parameter unused in the last micro-step."""
+    from torch.nn.parallel import DistributedDataParallel as TorchDDP
+
+    import distributed as dist
+
+    dist.init_process_group(rank, world_size, "gloo")
+    torch.manual_seed(5)
+    ours_m = _ScrambledNet()
+    torch.manual_seed(5)
+    ref_m = _ScrambledNet()
+    # positional tail in torch's order: output_device, dim, broadcast_buffers, init_sync, process_group, bucket_cap_mb
+    ours = dist.prepare_ddp_model(ours_m, [rank], None, 0, True, True, None, 0.001,
+                                  first_bucket_mb=0.0002, max_collective_mb=0.001)
+    ref = TorchDDP(ref_m, find_unused_parameters=True)
+    res = {"cap_bytes": ours._bucket_bytes, "buckets_before": [list(b) for b in ours._bucket_params]}
+    o1 = torch.optim.SGD(ours.parameters(), 0.1)
+    o2 = torch.optim.SGD(ref.parameters(), 0.1)
+    g = torch.Generator().manual_seed(11 + rank)
+    ready1 = None
+    for step in range(4):
+        x = torch.randn(8, 6, generator=g)
+        y = torch.randint(0, 3, (8,), generator=g)
+        for m, o in ((ours, o1), (ref, o2)):
+            o.zero_grad()
+            nn.functional.cross_entropy(m(x), y).backward()
+            o.step()
+        if step == 0:
+            ready1 = [int(i) for i in ours.reducer.ready_order()]
+    res["rebuilt"] = ours.buckets_rebuilt
+    res["ready_first_iteration"] = ready1
+    res["buckets_after"] = [list(b) for b in ours._bucket_params]
+    res["launch_positions"] = [int(i) for i in ours.reducer.launch_positions()]
+    res["slices"] = [int(i) for i in ours.reducer.slices_per_bucket()]
+    res["grads_are_views"] = all(
+        p.grad is not None and any(p.grad.untyped_storage().data_ptr() == a.untyped_storage().data_ptr() for a in ours.grad_arenas())
+        for p in ours.parameters())
+    res["max_param_diff"] = max(float((a - b).abs().max()) for a, b in zip(ours.module.parameters(), ref.module.parameters()))
+    # no_sync: `skipped` gets a gradient in the first micro-step only; the synced step must still reduce it
+    ours.zero_grad(set_to_none=True)
+    x = torch.full((2, 6), 0.5 + rank)
+    with ours.no_sync():
+        ours(x, use_skipped=True).sum().backward()
+    local = ours.module.skipped.bias.grad.clone()
+    gathered = [torch.zeros_like(local) for _ in range(world_size)]
+    torch.distributed.all_gather(gathered, local)
+    ours(x, use_skipped=False).sum().backward()
+    res["skipped_expected"] = (sum(gathered) / world_size).tolist()
+    res["skipped_got"] = ours.module.skipped.bias.grad.tolist()
+    _dump(out_dir, rank, res)
+    dist.cleanup()
+
+
+def hang_worker(rank, world_size, out_dir):
+    """Rank 1 stops making progress inside a step while rank 0 waits for it in a collective."""
+    import distributed as dist
+
+    dist.init_process_group(rank, world_size, "gloo")
+    t = torch.ones(2)
+    dist.all_reduce(t)          # collective #1 on both ranks
+    if rank == 1:
+        time.sleep(120)         # "hung": never reaches collective #2
+    dist.all_reduce(t)
     dist.cleanup()

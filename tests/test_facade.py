@@ -176,7 +176,7 @@ def test_launcher_refuses_more_ranks_than_gpus_unless_sharing_is_requested(monke
     with pytest.raises(ValueError, match="exceeds"):
         launcher.launch(lambda *a: None, nprocs=2)
 
-    def fake_spawn(fn, args, nprocs, env_per_rank, pin_cpus, join):
+    def fake_spawn(fn, args, nprocs, env_per_rank, pin_cpus, join, monitor=None):
         calls["env"] = env_per_rank
 
     monkeypatch.setattr(launcher, "spawn", fake_spawn)
@@ -230,3 +230,60 @@ def test_linear_module_impl_switch_keeps_parameters_and_cpu_path():
     assert list(a.state_dict()) == ["weight", "bias"] and "impl=library" in repr(b)
     with pytest.raises(ValueError):
         Linear(4, 4, impl="other")
+
+
+def test_every_binding_mode_gives_each_rank_its_own_gpu(monkeypatch):
+    """For each DIST_GPU_BINDING mode, the (visible list, local index) pair a rank ends up with names a
+    different physical GPU per rank, and in rotate mode every peer stays visible."""
+    from distributed_pytorch_amd.parallel.launcher import child_device_env
+
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    ids = [str(i) for i in range(8)]
+    for mode in ("rotate", "exclusive", "index"):
+        physical = []
+        for r in range(8):
+            e = child_device_env(ids, r, mode)
+            visible = e.get("HIP_VISIBLE_DEVICES", ",".join(ids)).split(",")
+            physical.append(visible[int(e["DIST_LOCAL_DEVICE"])])
+            if mode == "rotate":
+                assert sorted(visible) == ids
+            if mode == "exclusive":
+                assert visible == [str(r)]
+        assert physical == ids, mode
+
+
+def test_local_device_index_paths(monkeypatch):
+    """DIST_LOCAL_DEVICE (our launcher) wins, then LOCAL_RANK (torch.distributed.run), then the rank."""
+    import torch
+
+    from distributed_pytorch_amd.parallel import process_group as pg
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("DIST_LOCAL_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert pg.local_device_index(5) == 5
+    assert pg.local_device_index(11) == 3            # more ranks than devices wraps (gloo sharing)
+    monkeypatch.setenv("LOCAL_RANK", "6")
+    assert pg.local_device_index(0) == 6             # torchrun: every rank sees all GPUs, LOCAL_RANK picks
+    monkeypatch.setenv("DIST_LOCAL_DEVICE", "0")
+    assert pg.local_device_index(6) == 0             # our launcher rotated the visible list
+
+
+def test_device_uniqueness_check():
+    from distributed_pytorch_amd.parallel.process_group import check_device_map, format_device_map
+
+    ok = [(0, "node", "0000:05:00.0"), (1, "node", "0000:15:00.0"), (2, "other", "0000:05:00.0")]
+    assert check_device_map(ok) is None              # same bus id on another host is a different GPU
+    bad = ok + [(3, "node", "0000:15:00.0")]
+    msg = check_device_map(bad)
+    assert msg is not None and "ranks 1 and 3" in msg and "0000:15:00.0" in msg
+    assert format_device_map(ok).startswith("[rccl] rank->GPU (PCI bus id): 0->0000:05:00.0, 1->0000:15:00.0")
+
+
+def test_launcher_leaves_ipc_mode_alone(monkeypatch):
+    """Runtime variables that change how peer mappings are opened reach the workers as exported,
+    never invented by the launcher."""
+    import distributed_pytorch_amd.parallel.launcher as L
+
+    src = inspect.getsource(L.launch)
+    assert '"HSA_ENABLE_IPC_MODE_LEGACY":' not in src

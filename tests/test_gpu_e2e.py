@@ -47,13 +47,19 @@ def test_rccl_collectives_single_rank(rccl_group):
         assert torch.equal(x, torch.arange(17, device=DEV).to(dt))
     comm.barrier()
     # comm-stream path: fill on the compute stream, reduce on the comm stream, consume after wait
-    buf = torch.zeros(1 << 20, device=DEV)
-    for i in range(4):
+    bufs = [torch.zeros(1 << 20, device=DEV) for _ in range(4)]   # one bucket per slot, like the reducer
+    for i, buf in enumerate(bufs):
+        buf.add_(float(i + 1))
+        comm.all_reduce_async(buf, 4, i)
+    comm.wait_all_slots()
+    assert [b.sum().item() for b in bufs] == [float(i + 1) * (1 << 20) for i in range(4)]
+    # the same bucket again: the producer is ordered behind the previous collective by the wait above
+    for i, buf in enumerate(bufs):
         buf.add_(1.0)
         comm.all_reduce_async(buf, 4, i)
     comm.wait_all_slots()
-    assert buf.sum().item() == 4.0 * (1 << 20)
-    assert comm.num_async_ops() == 4
+    assert [b.sum().item() for b in bufs] == [float(i + 2) * (1 << 20) for i in range(4)]
+    assert comm.num_async_ops() == 8
 
 
 def test_ddp_wrapper_over_rccl_matches_plain_module(rccl_group):
@@ -65,7 +71,8 @@ def test_ddp_wrapper_over_rccl_matches_plain_module(rccl_group):
     twin = nn.Sequential(nn.Linear(64, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 10)).to(DEV)
     twin.load_state_dict(plain.state_dict())
     ddp = DistributedDataParallel(twin, device_ids=[0], bucket_cap_mb=0.1, first_bucket_mb=0.05)
-    assert ddp.reducer.num_buckets() >= 2
+    nb0 = ddp.reducer.num_buckets()
+    assert nb0 >= 2
     assert all(k.startswith("module.") for k in ddp.state_dict())
     o1 = torch.optim.AdamW(plain.parameters(), 1e-3)
     o2 = FusedAdamW(ddp.parameters(), 1e-3)
@@ -76,8 +83,8 @@ def test_ddp_wrapper_over_rccl_matches_plain_module(rccl_group):
             opt.zero_grad()
             nn.functional.cross_entropy(model(x), y).backward()
             opt.step()
-    assert ddp.reducer.num_backward_syncs() == 5
-    assert ddp.reducer.num_bucket_launches() == 5 * ddp.reducer.num_buckets()
+    assert ddp.num_backward_syncs() == 5
+    assert ddp.num_bucket_launches() == nb0 + 4 * ddp.reducer.num_buckets()  # re-planned once, after the first pass
     arena = ddp.grad_arenas()[0]
     lo, hi = arena.data_ptr(), arena.data_ptr() + arena.numel() * 4
     assert all(lo <= p.grad.data_ptr() < hi for p in ddp.parameters())  # grads are bucket views
@@ -96,6 +103,146 @@ def test_ddp_wrapper_over_rccl_matches_plain_module(rccl_group):
         torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-6)
 
 
+def test_rccl_debug_sync_overlap_timing_and_device_identity(rccl_group):
+    """DIST_DEBUG_SYNC serialises the reducer's communication-stream path (the stream is idle when
+    all_reduce_async returns), the overlap accounting reports sane numbers, and the device identity
+    used by the pre-init uniqueness check is a PCI bus id."""
+    import re
+
+    pg = rccl_group
+    comm = pg.get_comm()
+    C = type(comm)
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", C.device_bus_id(0)), C.device_bus_id(0)
+    assert re.fullmatch(r"\d+\.\d+\.\d+", C.version())
+    buf = torch.ones(8 << 20, device=DEV)
+    n0 = comm.num_async_ops()
+    assert not comm.debug_sync()
+    comm.set_debug_sync(True)
+    try:
+        for i in range(3):
+            buf.mul_(2.0)                       # work queued on the compute stream just before
+            comm.all_reduce_async(buf, 4, i)
+            assert comm.comm_stream_idle()      # already finished: nothing can overlap under the flag
+    finally:
+        comm.set_debug_sync(False)
+    comm.wait_all_slots()
+    assert comm.num_async_ops() == n0 + 3
+    assert buf[0].item() == 8.0
+    # overlap accounting
+    comm.set_timing(True)
+    for i in range(4):
+        buf.add_(1.0)
+        comm.all_reduce_async(buf, 4, i)
+    comm.wait_all_slots()
+    torch.cuda.synchronize()
+    busy, exposed, n = comm.read_timing()
+    comm.set_timing(False)
+    assert n == 4 and 0.0 < busy < 1000.0 and 0.0 <= exposed < 1000.0
+    assert comm.read_timing() == [0.0, 0.0, 0.0]
+
+
+def test_comm_stream_waits_on_a_busy_compute_stream(rccl_group):
+    """The fence the communication stream waits on must work when the compute stream has NOT reached it
+    yet (long kernels queued ahead), for bucket-sized buffers, repeatedly on one slot.  A wait on an
+    already-completed event proves nothing."""
+    comm = rccl_group.get_comm()
+    a = torch.randn(4096, 4096, device=DEV)
+    for mb in (1, 4, 16, 64, 128):
+        buf = torch.ones((mb << 20) // 2, device=DEV, dtype=torch.bfloat16)
+        for _ in range(8):
+            a = (a @ a).clamp_(-1, 1)          # ~10 ms of work ahead of the fence
+        buf.add_(1.0)
+        comm.all_reduce_async(buf, 4, 0)
+        comm.wait_all_slots()
+        buf.add_(1.0)                          # consumer on the compute stream
+        torch.cuda.synchronize()
+        assert buf[0].item() == 3.0 and buf[-1].item() == 3.0
+
+
+def test_full_width_gpt2_step_under_the_reducer(rccl_group):
+    """GPT-2 small width (768 / 12 heads / 1024 tokens, 2 layers) with the default bucket sizes: the
+    77 MB tied embedding gradient goes out as sliced all-reduces behind a backward pass that is still
+    running, and the wrapped model trains exactly like the plain one."""
+    from distributed_pytorch_amd.models import GPT2, GPT2Config
+    from distributed_pytorch_amd.ops import FusedAdamW
+    from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+    cfg = GPT2Config.small(block_size=1024)
+    cfg.n_layer = 2
+    torch.manual_seed(0)
+    plain = GPT2(cfg).to(DEV).bfloat16()
+    twin = GPT2(cfg).to(DEV).bfloat16()
+    twin.load_state_dict(plain.state_dict())
+    ddp = DistributedDataParallel(twin)
+    assert max(ddp.reducer.slices_per_bucket()) >= 2
+    o1 = FusedAdamW(plain.parameters(), 1e-4, master_weights=True)
+    o2 = FusedAdamW(ddp.parameters(), 1e-4, master_weights=True)
+    idx = torch.randint(0, cfg.vocab_size, (4, 1024), device=DEV)
+    tgt = torch.randint(0, cfg.vocab_size, (4, 1024), device=DEV)
+    for step in range(3):
+        losses = []
+        for model, opt in ((plain, o1), (ddp, o2)):
+            opt.zero_grad(set_to_none=True)
+            loss = model(idx, tgt)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        assert losses[0] == losses[1]
+    for (n, a), b in zip(plain.named_parameters(), ddp.module.parameters()):
+        assert torch.equal(a, b), n
+
+
+class _Scrambled(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.last = nn.Linear(256, 10)
+        self.first = nn.Linear(64, 256)
+        self.mid = nn.Linear(256, 256)
+
+    def forward(self, x):
+        return self.last(torch.relu(self.mid(torch.relu(self.first(x)))))
+
+
+def test_bucket_rebuild_and_packed_parameter_broadcast_on_gpu(rccl_group):
+    from distributed_pytorch_amd.ops import FusedAdamW
+    from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+    torch.manual_seed(0)
+    plain, twin = _Scrambled().to(DEV), _Scrambled().to(DEV)
+    twin.load_state_dict(plain.state_dict())
+    ddp = DistributedDataParallel(twin, bucket_cap_mb=0.1, first_bucket_mb=0.05, max_collective_mb=0.1)
+    nb = ddp.reducer.num_buckets()
+    before = [list(b) for b in ddp._bucket_params]
+    # initial parameter sync: one pack launch, one broadcast, one unpack launch per bucket
+    n0 = ddp.reducer.num_pack_launches()
+    ddp.reducer.broadcast_parameters(0)
+    assert ddp.reducer.num_pack_launches() - n0 == 2 * nb
+    for a, b in zip(plain.parameters(), ddp.module.parameters()):
+        assert torch.equal(a, b)
+    o1, o2 = torch.optim.AdamW(plain.parameters(), 1e-3), FusedAdamW(ddp.parameters(), 1e-3)
+    for step in range(4):
+        x = torch.randn(32, 64, device=DEV)
+        y = torch.randint(0, 10, (32,), device=DEV)
+        for model, opt in ((plain, o1), (ddp, o2)):
+            opt.zero_grad(set_to_none=(step % 2 == 0))   # both zeroing styles cross the rebuild
+            nn.functional.cross_entropy(model(x), y).backward()
+            opt.step()
+    assert ddp.buckets_rebuilt and [list(b) for b in ddp._bucket_params] != before
+    flat = [i for b in ddp._bucket_params for i in b]
+    assert flat == [int(i) for i in ddp.reducer.ready_order()]
+    sizes, total = [], 0
+    for b in ddp._bucket_params:
+        total += len(b)
+        sizes.append(total)
+    assert [int(i) for i in ddp.reducer.launch_positions()] == sizes
+    assert max(ddp.reducer.slices_per_bucket()) > 1
+    arena = ddp.grad_arenas()[0]
+    lo, hi = arena.data_ptr(), arena.data_ptr() + arena.numel() * 4
+    assert all(lo <= p.grad.data_ptr() < hi for p in ddp.parameters())
+    for a, b in zip(plain.parameters(), ddp.parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_gpt2_with_fused_nodes_under_the_reducer_matches_plain_training(rccl_group):
     """GPT-2 (tied embedding / lm-head weight, fused MLP, projection + attention and lm-head + loss nodes)
     wrapped in the data-parallel module: bucket hooks fire for every parameter, gradients live in the
@@ -110,7 +257,8 @@ def test_gpt2_with_fused_nodes_under_the_reducer_matches_plain_training(rccl_gro
     twin = GPT2(cfg).to(DEV).bfloat16()
     twin.load_state_dict(plain.state_dict())
     ddp = DistributedDataParallel(twin, device_ids=[0], bucket_cap_mb=0.25, first_bucket_mb=0.05)
-    assert ddp.reducer.num_buckets() >= 3
+    nb0 = ddp.reducer.num_buckets()
+    assert nb0 >= 3
     o1 = FusedAdamW(plain.parameters(), 1e-3, master_weights=True)
     o2 = FusedAdamW(ddp.parameters(), 1e-3, master_weights=True)
     g = torch.Generator().manual_seed(1)
@@ -124,8 +272,10 @@ def test_gpt2_with_fused_nodes_under_the_reducer_matches_plain_training(rccl_gro
             loss.backward()
             opt.step()
             losses[k].append(loss.item())
-    assert ddp.reducer.num_backward_syncs() == 5
-    assert ddp.reducer.num_bucket_launches() == 5 * ddp.reducer.num_buckets()
+    assert ddp.num_backward_syncs() == 5
+    assert ddp.num_bucket_launches() == nb0 + 4 * ddp.reducer.num_buckets()
+    # the fused nodes hand several gradients over out of registration order: the layout follows them
+    assert ddp.buckets_rebuilt and [i for b in ddp._bucket_params for i in b] == [int(i) for i in ddp.reducer.ready_order()]
     assert losses[0] == losses[1], losses
     for (n, a), b in zip(plain.named_parameters(), ddp.module.parameters()):
         assert torch.equal(a, b), n

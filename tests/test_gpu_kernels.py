@@ -127,6 +127,50 @@ def test_fused_adamw_clipping():
         torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
 
 
+def test_grad_norm_is_fixed_order_and_exact():
+    """Sum of squares over many tensors (several dtypes, sizes beyond one table): two stages with a
+    fixed summation order, so repeated runs are bit-identical, and the value matches fp64."""
+    Cx = C()
+    torch.manual_seed(11)
+    ts = [torch.randn(n, device=DEV).to(dt) for n, dt in
+          [(1, torch.float32), (8191, torch.bfloat16), (300_000, torch.float32), (70_001, torch.bfloat16)] + [(1000 + i, torch.float32) for i in range(40)]]
+    outs = []
+    for _ in range(3):
+        out = torch.full((1,), 123.0, device=DEV)   # stale content must be overwritten, not added to
+        Cx.grad_sumsq(ts, out)
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    ref = sum(float(t.double().pow(2).sum()) for t in ts)
+    assert abs(outs[0].item() - ref) / ref < 1e-5
+
+
+def test_fused_adamw_channels_last_parameters():
+    """Convolution weights kept in channels-last memory format (the ResNet path): parameter, gradient and
+    moments are walked in storage order, with gradients arriving in either memory format."""
+    from distributed_pytorch_amd.ops import FusedAdamW
+
+    torch.manual_seed(5)
+    ref_p = [torch.randn(16, 8, 3, 3, dtype=torch.float64).requires_grad_(), torch.randn(16, dtype=torch.float64).requires_grad_()]
+    my_p = [ref_p[0].detach().float().to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(),
+            ref_p[1].detach().float().to(DEV).requires_grad_()]
+    assert not my_p[0].is_contiguous()
+    ref = torch.optim.AdamW(ref_p, lr=1e-2, weight_decay=0.1)
+    mine = FusedAdamW(my_p, lr=1e-2, weight_decay=0.1, max_grad_norm=5.0)
+    for step in range(4):
+        for rp, mp in zip(ref_p, my_p):
+            g = torch.randn(rp.shape, dtype=torch.float64)
+            rp.grad = g
+            gd = g.float().to(DEV)
+            # even steps: gradient in the parameter's memory format; odd steps: plain contiguous
+            mp.grad = gd.contiguous(memory_format=torch.channels_last) if (gd.dim() == 4 and step % 2 == 0) else gd
+        torch.nn.utils.clip_grad_norm_(ref_p, 5.0)
+        ref.step()
+        mine.step()
+    assert not my_p[0].is_contiguous() and my_p[0].is_contiguous(memory_format=torch.channels_last)
+    for rp, mp in zip(ref_p, my_p):
+        torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
+
+
 # ----------------------------------------------------------------------------- softmax cross-entropy
 @pytest.mark.parametrize("N,Cc,ld", [(8, 4, 4), (1, 4, 4), (1000, 4, 4), (37, 10, 10), (64, 1000, 1000), (5, 1001, 1001),
                                      (33, 5000, 5000), (16, 50257, 50304), (3, 50257, 50257)])

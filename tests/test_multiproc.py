@@ -228,3 +228,66 @@ def test_example_training_script_two_ranks_checkpoint_and_resume(tmp_path):
     assert "resumed from" in second.stdout and "at step 8" in second.stdout
     recs2 = [json.loads(ln) for ln in second.stdout.splitlines() if ln.startswith("{")]
     assert [r["step"] for r in recs2] == [12]
+
+
+def test_bucket_rebuild_slicing_and_positional_args(tmp_path):
+    dist.launch(mp_workers.ddp_rebuild_worker, str(tmp_path), nprocs=2)
+    r0, r1 = _read(tmp_path, 2)
+    for r in (r0, r1):
+        assert r["cap_bytes"] == int(0.001 * (1 << 20))          # bucket_cap_mb arrived positionally
+        assert r["rebuilt"] and r["buckets_after"] != r["buckets_before"]
+        flat = [i for b in r["buckets_after"] for i in b]
+        assert flat == r["ready_first_iteration"]                 # bucket k holds the k-th group of ready gradients
+        # ... so every bucket goes out the moment its last gradient arrives
+        sizes, total = [], 0
+        for b in r["buckets_after"]:
+            total += len(b)
+            sizes.append(total)
+        assert r["launch_positions"] == sizes
+        assert max(r["slices"]) > 1                               # the 16x64 layer exceeds the collective cap
+        assert r["grads_are_views"]
+        assert r["max_param_diff"] < 1e-6
+        assert r["skipped_got"] == pytest.approx(r["skipped_expected"], rel=1e-6)
+    assert r0["buckets_after"] == r1["buckets_after"]
+
+
+def test_hung_rank_is_named_and_job_is_killed(tmp_path, monkeypatch):
+    from distributed_pytorch_amd.parallel.launcher import ProcessHungException
+
+    monkeypatch.setenv("DIST_HANG_TIMEOUT_S", "3")
+    monkeypatch.setenv("DIST_HEARTBEAT_S", "0.2")
+    t0 = time.time()
+    with pytest.raises(ProcessHungException) as ei:
+        dist.launch(mp_workers.hang_worker, str(tmp_path), nprocs=2)
+    took = time.time() - t0
+    assert ei.value.ranks == [1]
+    assert "rank 1 (collective #1)" in str(ei.value) and "#2" in str(ei.value)
+    assert took < 60, took      # the sleeping rank would have held the job for 120 s
+
+
+def test_hang_monitor_decisions():
+    from distributed_pytorch_amd.parallel.heartbeat import HangMonitor
+
+    now = [0.0]
+    mon = HangMonitor(None, 3, timeout_s=10, stall_s=0, clock=lambda: now[0])
+    assert mon.observe({0: (1, "run"), 1: (1, "run")}) is None                      # rank 2 has not joined yet
+    assert mon.observe({0: (5, "run"), 1: (5, "run"), 2: (5, "run")}) is None
+    now[0] = 100.0
+    assert mon.observe({0: (5, "run"), 1: (5, "run"), 2: (5, "run")}) is None       # equal counters: idle, not hung
+    assert mon.observe({0: (6, "run"), 1: (5, "run"), 2: (6, "run")}) is not None   # 1 has been at #5 for 100 s
+    mon2 = HangMonitor(None, 2, timeout_s=10, stall_s=0, clock=lambda: now[0])
+    assert mon2.observe({0: (1, "run"), 1: (1, "run")}) is None
+    now[0] += 5
+    assert mon2.observe({0: (2, "run"), 1: (1, "run")}) is None                     # behind, but only for 5 s
+    now[0] += 6
+    v = mon2.observe({0: (2, "run"), 1: (1, "run")})
+    assert v is not None and v.ranks == [1] and v.kind == "lag"
+    mon3 = HangMonitor(None, 2, timeout_s=10, stall_s=0, clock=lambda: now[0])
+    mon3.observe({0: (3, "run"), 1: (9, "done")})
+    now[0] += 100
+    assert mon3.observe({0: (3, "run"), 1: (9, "done")}) is None                    # a finished rank is not waited for
+    mon4 = HangMonitor(None, 2, timeout_s=0, stall_s=20, clock=lambda: now[0])
+    mon4.observe({0: (4, "run"), 1: (4, "run")})
+    now[0] += 21
+    v = mon4.observe({0: (4, "run"), 1: (4, "run")})
+    assert v is not None and v.kind == "stall" and v.ranks == [0, 1]

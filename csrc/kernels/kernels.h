@@ -151,6 +151,17 @@ void launch_outer_wgrad(const void* dy, const void* x, void* dw, void* db, float
 //   db[N] = colsum(dy[M,N])  (also used by the large-GEMM path)
 void launch_colsum(const void* dy, void* db, float* workspace, long long M, long long N, int dtype,
                    hipStream_t stream);
+// Linear(1, H) -> act -> Linear(H, N <= 16) without materialising the hidden layer (rank1_mlp.hip).
+//   forward : y[M,N] = b2 + act(x w1^T + b1) W2^T        x: [M] scalars, w1/b1: [H], W2: [N,H]
+//   backward: grads (length rank1_mlp_bwd_len(H,N), NT = 4 | 8 | 16 >= N) holds
+//             dW2 rows at [n*H, (n+1)*H), dw1 at [NT*H, ...), db1 at [(NT+1)*H, ...), db2 at [(NT+2)*H, +N);
+//             partial: rank1_mlp_bwd_chunks(M,H) * rank1_mlp_bwd_len(H,N) floats of workspace.
+void launch_rank1_mlp_fwd(const void* x, const void* w1, const void* b1, const void* W2, const void* b2, void* y,
+                          long long M, long long H, long long N, int dtype, int act, hipStream_t stream);
+int rank1_mlp_bwd_chunks(long long M, long long H);
+long long rank1_mlp_bwd_len(long long H, long long N);
+void launch_rank1_mlp_bwd(const void* dy, const void* x, const void* w1, const void* b1, const void* W2, float* partial,
+                          void* grads, long long M, long long H, long long N, int dtype, int act, hipStream_t stream);
 //   out[i] = sum over c < chunks of partial[c][i]   (fixed order)
 void launch_reduce_partials(const float* partial, void* out, long long len, int chunks, int dtype,
                             hipStream_t stream);

@@ -373,6 +373,65 @@ std::tuple<Tensor, c10::optional<Tensor>> linear_forward(Tensor x, Tensor w, c10
   return {y, pre};
 }
 
+// ------------------------------------------------------------------ Linear(1,H) -> act -> Linear(H,N<=16), fused
+namespace {
+const void* opt_ptr(const c10::optional<Tensor>& t, const Tensor& like, int64_t numel, const char* what) {
+  if (!t.has_value() || !t->defined()) return nullptr;
+  check_gpu(*t, what);
+  TORCH_CHECK(t->numel() == numel && t->scalar_type() == like.scalar_type() && t->get_device() == like.get_device(),
+              "rank1_mlp: ", what, " must hold ", numel, " elements of the weight dtype on the same device");
+  return t->data_ptr();
+}
+void check_rank1(const Tensor& x, const Tensor& w1, const Tensor& W2, int64_t act) {
+  check_gpu(x, "x");
+  check_gpu(w1, "w1");
+  check_gpu(W2, "W2");
+  TORCH_CHECK(W2.dim() == 2 && w1.numel() == W2.size(1), "rank1_mlp: w1 [H] (or [H,1]) and W2 [N,H] expected");
+  TORCH_CHECK(x.dim() <= 2 && (x.dim() < 2 || x.size(1) == 1), "rank1_mlp: x must be [M] or [M,1]");
+  TORCH_CHECK(W2.size(0) >= 1 && W2.size(0) <= 16, "rank1_mlp: 1 <= N <= 16 outputs");
+  TORCH_CHECK(W2.size(1) < (1ll << 30), "rank1_mlp: hidden size too large");
+  TORCH_CHECK(x.scalar_type() == w1.scalar_type() && x.scalar_type() == W2.scalar_type(), "rank1_mlp: dtypes differ");
+  TORCH_CHECK(x.get_device() == w1.get_device() && x.get_device() == W2.get_device(), "rank1_mlp: device mismatch");
+  TORCH_CHECK(kdtype(x) >= 0, "rank1_mlp: unsupported dtype");
+  TORCH_CHECK(act == kernels::kActNone || act == kernels::kActRelu, "rank1_mlp: activation must be none or relu");
+}
+}  // namespace
+
+Tensor rank1_mlp_forward(Tensor x, Tensor w1, c10::optional<Tensor> b1, Tensor W2, c10::optional<Tensor> b2, int64_t act) {
+  check_rank1(x, w1, W2, act);
+  const int64_t M = x.numel(), H = W2.size(1), N = W2.size(0);
+  const void* b1p = opt_ptr(b1, w1, H, "b1");
+  const void* b2p = opt_ptr(b2, w1, N, "b2");
+  Tensor y = at::empty({M, N}, x.options());
+  DevGuard g(x);
+  kernels::launch_rank1_mlp_fwd(x.data_ptr(), w1.data_ptr(), b1p, W2.data_ptr(), b2p, y.data_ptr(), M, H, N, kdtype(x),
+                                static_cast<int>(act), stream_of(x));
+  return y;
+}
+
+// Returns (dw1 [H,1], db1 [H], dW2 [N,H], db2 [N]) as views of one buffer.
+std::tuple<Tensor, Tensor, Tensor, Tensor> rank1_mlp_backward(Tensor dy, Tensor x, Tensor w1, c10::optional<Tensor> b1, Tensor W2, int64_t act) {
+  check_rank1(x, w1, W2, act);
+  check_gpu(dy, "dy");
+  const int64_t M = x.numel(), H = W2.size(1), N = W2.size(0);
+  TORCH_CHECK(dy.dim() == 2 && dy.size(0) == M && dy.size(1) == N && dy.scalar_type() == x.scalar_type() && dy.get_device() == x.get_device(),
+              "rank1_mlp_backward: dy must be [M,N] in the dtype and on the device of x");
+  const void* b1p = opt_ptr(b1, w1, H, "b1");
+  const int64_t len = kernels::rank1_mlp_bwd_len(H, N);
+  const int64_t NT = (len - 2 * H) / (H + 1);
+  Tensor grads = at::empty({len}, x.options());
+  DevGuard g(x);
+  if (M == 0) {
+    grads.zero_();
+  } else {
+    Tensor partial = at::empty({static_cast<int64_t>(kernels::rank1_mlp_bwd_chunks(M, H)) * len}, x.options().dtype(at::kFloat));
+    kernels::launch_rank1_mlp_bwd(dy.data_ptr(), x.data_ptr(), w1.data_ptr(), b1p, W2.data_ptr(), partial.data_ptr<float>(),
+                                  grads.data_ptr(), M, H, N, kdtype(x), static_cast<int>(act), stream_of(x));
+  }
+  return {grads.narrow(0, NT * H, H).view({H, 1}), grads.narrow(0, (NT + 1) * H, H), grads.narrow(0, 0, N * H).view({N, H}),
+          grads.narrow(0, (NT + 2) * H, N)};
+}
+
 // Gradients of y = x W^T + b given g = dL/d(xW^T+b).  Returns (dx or None, dW, db or None).
 std::tuple<c10::optional<Tensor>, Tensor, c10::optional<Tensor>> linear_backward(Tensor g, Tensor x, Tensor w, bool need_dx, bool need_db) {
   check_gpu(g, "grad");
@@ -684,6 +743,8 @@ void init_ops(py::module_& m) {
   });
   m.def("linear_forward", &linear_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("act") = 0, py::arg("save_pre_act") = false);
   m.def("linear_backward", &linear_backward, py::arg("grad"), py::arg("x"), py::arg("weight"), py::arg("need_dx") = true, py::arg("need_db") = true);
+  m.def("rank1_mlp_forward", &rank1_mlp_forward, py::arg("x"), py::arg("w1"), py::arg("b1"), py::arg("W2"), py::arg("b2"), py::arg("act") = 0);
+  m.def("rank1_mlp_backward", &rank1_mlp_backward, py::arg("dy"), py::arg("x"), py::arg("w1"), py::arg("b1"), py::arg("W2"), py::arg("act") = 0);
   m.def("act_backward", &act_backward, py::arg("dy"), py::arg("saved"), py::arg("act"), py::arg("need_db") = false);
   m.def("colsum", &colsum);
   m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),

@@ -13,6 +13,7 @@ import torch.nn as nn
 from torch.utils.data import Dataset
 
 from ..ops.linear import Linear
+from ..ops.rank1_mlp import rank1_mlp, rank1_mlp_supported
 
 
 class DummyDataset(Dataset):
@@ -30,13 +31,22 @@ class DummyDataset(Dataset):
 
 
 class DummyModel(nn.Module):
-    """``lin2(lin1(x))`` with no nonlinearity in between (as in the reference)."""
+    """``lin2(lin1(x))`` with no nonlinearity in between (as in the reference).
 
-    def __init__(self, in_dim: int, hidden_dim: int, n_classes: int, native: bool = True, act=None):
+    With ``native=True`` on the GPU and ``in_dim == 1`` (the reference's configuration) both layers run
+    as one fused node that keeps the hidden activation in registers (``ops/rank1_mlp.py``);
+    ``fused=False`` keeps them as two separately executed linear layers."""
+
+    def __init__(self, in_dim: int, hidden_dim: int, n_classes: int, native: bool = True, act=None, fused: bool = True):
         super().__init__()
         layer = Linear if native else nn.Linear
         self.lin1 = layer(in_dim, hidden_dim) if not (native and act) else Linear(in_dim, hidden_dim, act=act)
         self.lin2 = layer(hidden_dim, n_classes)
+        self.native = bool(native)
+        self.fused = bool(fused)
+        self.act = act
 
     def forward(self, x):
+        if self.native and self.fused and rank1_mlp_supported(x, self.lin1.weight, self.lin2.weight, self.act):
+            return rank1_mlp(x, self.lin1.weight, self.lin1.bias, self.lin2.weight, self.lin2.bias, self.act)
         return self.lin2(self.lin1(x))

@@ -171,6 +171,57 @@ def test_fused_adamw_channels_last_parameters():
         torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
 
 
+# ----------------------------------------------------------------------------- fused Linear(1,H) -> Linear(H,N)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H,N,act", [(1000, 300, 4, None), (65, 4096, 4, "relu"), (4096, 513, 3, None), (257, 256, 10, "relu"),
+                                       (64, 64, 16, None), (1, 7, 1, "relu")])
+def test_rank1_mlp_matches_fp64_reference(dtype, M, H, N, act):
+    """Both directions of the fused two-layer node against an fp64 evaluation of the same parameters,
+    including hidden sizes that are not a multiple of the workgroup, N below the register tile and ReLU."""
+    from distributed_pytorch_amd.ops.rank1_mlp import rank1_mlp
+
+    torch.manual_seed(M + H + N)
+    x = torch.rand(M, 1, device=DEV).to(dtype)
+    w1 = (torch.randn(H, 1, device=DEV) * 1.5).to(dtype).requires_grad_()
+    b1 = torch.randn(H, device=DEV).to(dtype).requires_grad_()
+    w2 = (torch.randn(N, H, device=DEV) / H ** 0.5).to(dtype).requires_grad_()
+    b2 = torch.randn(N, device=DEV).to(dtype).requires_grad_()
+    y = rank1_mlp(x, w1, b1, w2, b2, act)
+    dy = torch.randn(M, N, device=DEV).to(dtype)
+    y.backward(dy)
+    ref_in = [t.detach().double().requires_grad_() for t in (w1, b1, w2, b2)]
+    h = x.double() @ ref_in[0].t() + ref_in[1]
+    if act == "relu":
+        h = torch.relu(h)
+    yr = h @ ref_in[2].t() + ref_in[3]
+    yr.backward(dy.double())
+    t = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(y.double(), yr, **t)
+    for got, ref, name in zip((w1, b1, w2, b2), ref_in, ("dw1", "db1", "dW2", "db2")):
+        scale = max(1.0, float(ref.grad.abs().max()))
+        assert got.grad.shape == ref.grad.shape, name
+        err = float((got.grad.double() - ref.grad).abs().max()) / scale
+        assert err < (2e-2 if dtype == torch.bfloat16 else 1e-4), (name, err)
+
+
+def test_rank1_mlp_without_biases_and_determinism():
+    from distributed_pytorch_amd.ops.rank1_mlp import rank1_mlp
+
+    torch.manual_seed(0)
+    x = torch.rand(5000, 1, device=DEV)
+    w1 = torch.randn(1024, 1, device=DEV, requires_grad=True)
+    w2 = torch.randn(4, 1024, device=DEV, requires_grad=True)
+    grads = []
+    for _ in range(2):
+        w1.grad = w2.grad = None
+        y = rank1_mlp(x, w1, None, w2, None)
+        y.square().sum().backward()
+        grads.append((w1.grad.clone(), w2.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])   # fixed-order reductions
+    yr = (x.double() @ w1.detach().double().t()) @ w2.detach().double().t()
+    torch.testing.assert_close(y.double(), yr, rtol=1e-4, atol=1e-3)
+
+
 # ----------------------------------------------------------------------------- softmax cross-entropy
 @pytest.mark.parametrize("N,Cc,ld", [(8, 4, 4), (1, 4, 4), (1000, 4, 4), (37, 10, 10), (64, 1000, 1000), (5, 1001, 1001),
                                      (33, 5000, 5000), (16, 50257, 50304), (3, 50257, 50257)])

@@ -124,12 +124,17 @@ def build_gpu(force=False, verbose=False, jobs_n=8):
     ]
     plain_flags = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + str(CSRC)]
 
+    # Per-file additions.  attention.hip: its maxima run over raw matrix-core outputs (no NaN can occur:
+    # masked scores are -inf, which these flags leave alone), and without -fno-honor-nans every fmaxf gets a
+    # canonicalising v_max in front; SLP packing of adjacent f32 operations into v_pk_*_f32 is off because the
+    # packed forms issue slower than two plain instructions next to MFMAs.
+    per_file = {"attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
     objs, cmds = [], []
     for s in kernels:
         o = BUILD / "gpu" / (s.stem + ".hip.o")
         objs.append(o)
         if _needs_build(s, o, hdr, force):
-            cmds.append([hipcc, *kernel_flags, "-c", s, "-o", o])
+            cmds.append([hipcc, *kernel_flags, *per_file.get(s.name, []), "-c", s, "-o", o])
     for s in torch_cpp:
         o = BUILD / "gpu" / (s.stem + ".cpp.o")
         objs.append(o)

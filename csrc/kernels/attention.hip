@@ -69,6 +69,7 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
   return r;
 }
 
+
 struct AttnParams {
   const u16* q;  // element (b, t, h, d) at q[(b*T + t) * row_stride + h*64 + d]; same for k, v
   const u16* k;
@@ -78,35 +79,45 @@ struct AttnParams {
   long long row_stride;  // elements between consecutive t of q/k/v (3*H*64 for a packed projection)
   int B, H, T;
   float scale_log2;      // softmax scale * log2(e)
+  int per_cu;            // resident workgroups per CU of this launch (priority balancing)
 };
 
-// Workgroup -> (block index within the head, batch*head).  Hardware hands consecutive workgroup ids
-// to the 8 XCDs round-robin and every XCD has its own L2, so the blocks of one head -- which all
-// stream the same K / V (or Q / dO) rows -- are given ids that land on ONE XCD: the id is mapped
-// bijectively to v = (position of this id inside its XCD's run), and v is split as
-// (head = v / blocks_per_head, block = v % blocks_per_head).
-__device__ __forceinline__ void head_block_of_workgroup(int blocks_per_head, int& block, int& bh) {
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  bh = v / blocks_per_head;
-  block = v - bh * blocks_per_head;
-}
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-// Maximum of a strip's 16 scaled scores.  The inputs are products (already canonical floats), so the
-// compiler emits bare v_max3_f32 without the NaN-quieting moves it wraps around fmaxf of raw
-// matrix-core outputs.  (Inline-asm max instructions are not an option here: the hazard
-// recogniser does not see inside them, and a VALU read too soon after an MFMA write returns stale
-// accumulator data.)
-__device__ __forceinline__ float max16(const f32x2 (&t)[8]) {
-  float m = fmaxf(fmaxf(t[0][0], t[0][1]), t[1][0]);
-#pragma unroll
-  for (int i = 1; i < 7; ++i) m = fmaxf(fmaxf(m, t[i][1]), t[i + 1][0]);
-  return fmaxf(m, t[7][1]);
+// Work items.  Under the causal mask, block i of a head (128 queries, or 128 keys in the dK/dV kernel)
+// costs i + 1 units (resp. nqb - i), so blocks are handed out in PAIRS (i, nqb-1-i) of equal total cost:
+// an item is one pair of one (batch, head), ceil(nqb / 2) items per head (the middle block is alone when
+// nqb is odd).  The kernels are persistent: a launch has a fixed number of workgroups (a multiple of 8,
+// a few per CU) and workgroup w takes items w, w + G, w + 2G, ... of the XCD-grouped order below, so all
+// workgroups carry the same load, nothing is left for a ragged tail, and a workgroup's launch cost is paid
+// once per kernel instead of once per block.
+// The hardware's issue arbitration favours the OLDER of the workgroups that share a CU: measured on the
+// persistent forward kernel at two workgroups per CU, the first-dispatched half of the grid finished its
+// (equal) share in 79 us and the second half in 97 us, the last 18 us at half occupancy; raising the
+// younger half's priority once simply swaps the roles (96 / 79 us).  So the priority ALTERNATES: in
+// every step of its tile loop a workgroup runs at priority 1 when (step + dispatch round) is odd and 0
+// otherwise, which gives the CU's resident workgroups the upper hand in turns.  `dispatch_round()` =
+// which of the CU's resident workgroups this one is (ids are handed out round by round).
+__device__ __forceinline__ int dispatch_round(int per_cu) {
+  const int per_round = gridDim.x / (per_cu > 0 ? per_cu : 1);
+  return per_round > 0 ? static_cast<int>(blockIdx.x) / per_round : 0;
 }
+__device__ __forceinline__ void take_turns(int step_plus_round) {
+  if (step_plus_round & 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
+// Item index -> (pair index within the head, batch*head): hardware hands consecutive workgroup ids to the
+// 8 XCDs round-robin and every XCD has its own L2, so the items of one head -- which all stream the same
+// K / V (or Q / dO) rows -- are numbered such that they land on ONE XCD: ids congruent mod 8 form one
+// contiguous run of (head, pair) positions.
+__device__ __forceinline__ void item_of_index(int idx, int n_items, int items_per_head, int& pair, int& bh) {
+  const int q = n_items >> 3, r = n_items & 7, xcd = idx & 7;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (idx >> 3);
+  bh = v / items_per_head;
+  pair = v - bh * items_per_head;
+}
+
 // Combine a value across the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) with the
 // gfx950 row-swap instructions: two VALU ops per step instead of an LDS round trip (ds_bpermute).
 __device__ __forceinline__ float groups_max(float x) {
@@ -208,9 +219,24 @@ __device__ __forceinline__ void store_rows_staged(char* strip, const f32x4 (&acc
 }
 
 // Online-softmax update of one 16-query strip: scores s (S^T accumulators of the strip's four
-// 16-key tiles) -> bf16 probabilities packed as the two B operands of the P.V product.
+// 16-key tiles) -> bf16 probabilities packed as the two B operands of the P.V product.  The loop is
+// bound by vector issue slots, not by the matrix pipe, so the work per score is one v_fma_f32 and one
+// v_exp_f32 (plain, not packed, instructions: packed f32 VALU ops issue at less than half the rate of
+// two plain ones next to matrix instructions):
+//  * the running maximum m is kept in the scaled (log2) domain but taken over the RAW scores, so the
+//    softmax scale rides in the exponent's FMA: p = exp2(s * c - m);
+//  * m only moves when a score exceeds it by more than kDeferLog2 (probabilities stay below
+//    2^kDeferLog2, harmless in fp32 sums and bf16 operands).  The common case is decided per lane -- if
+//    no lane of the wave holds a score above the threshold, no query's maximum moved -- so the
+//    cross-lane maximum and the rescale of the output only run in the rare tile where something moved;
+//  * the row sum is not added up on the VALU at all: see fwd_tile.
+// (Measured and dropped: pre-scaled Q with -m as the score product's initial accumulator, which would
+// leave only the v_exp_f32 -- the compiler copies the initial value into the result registers first,
+// 16 moves per strip, and the longer live ranges cost a wave of occupancy.)
+constexpr float kDeferLog2 = 8.f;
+
 template <bool MASK>
-__device__ __forceinline__ void softmax_strip(f32x4 (&s)[4], f32x4 (&o)[4], float& m, float& l, bf16x8 (&pf)[2], int rel, float c) {
+__device__ __forceinline__ void softmax_strip(f32x4 (&s)[4], f32x4 (&o)[4], f32x4& lsum, float& m, bf16x8 (&pf)[2], int rel, float c) {
   if (MASK) {  // key index 16t + e of this lane group is allowed while 16t + e <= rel
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -218,47 +244,46 @@ __device__ __forceinline__ void softmax_strip(f32x4 (&s)[4], f32x4 (&o)[4], floa
       for (int e = 0; e < 4; ++e)
         if (16 * t + e > rel) s[t][e] = -__builtin_huge_valf();
   }
-  // scaled scores (log2 domain), row maximum, then one packed subtract + exp per pair
-  const f32x2 cc = {c, c};
-  f32x2 t2[8];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) t2[2 * t + h2] = f32x2{s[t][2 * h2], s[t][2 * h2 + 1]} * cc;  // v_pk_mul_f32
-  const float mx = groups_max(max16(t2));
-  const float m_new = fmaxf(m, mx);
-  const float alpha = fast_exp2(m - m_new);
-  m = m_new;
-  const f32x2 mm = {m_new, m_new};
-  f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    f32x2 x = t2[i] - mm;  // v_pk_add_f32
-    x[0] = fast_exp2(x[0]);
-    x[1] = fast_exp2(x[1]);
-    ps2 += x;
-    t2[i] = x;
-  }
-  l = fmaf(l, alpha, ps2[0] + ps2[1]);  // per-lane partial sum; combined across the 4 lane groups at the end
-  if (__any(alpha != 1.f)) {            // the running maximum moved for some query of this wave
+  float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+  mx = fmaxf(fmaxf(mx, s[0][3]), s[1][0]);
+  mx = fmaxf(fmaxf(mx, s[1][1]), s[1][2]);
+  mx = fmaxf(fmaxf(mx, s[1][3]), s[2][0]);
+  mx = fmaxf(fmaxf(mx, s[2][1]), s[2][2]);
+  mx = fmaxf(fmaxf(mx, s[2][3]), s[3][0]);
+  mx = fmaxf(fmaxf(mx, s[3][1]), s[3][2]);
+  mx = fmaxf(mx, s[3][3]) * c;          // c > 0: this lane's maximum of the scaled scores
+  if (__any(mx > m + kDeferLog2)) {     // rare after the first tile: some query's maximum moved a lot
+    const float mg = groups_max(mx);    // the query's maximum over all four lane groups
+    const float m_new = mg > m + kDeferLog2 ? mg : m;
+    const float alpha = fast_exp2(m - m_new);
+    m = m_new;
 #pragma unroll
     for (int td = 0; td < 4; ++td)
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[td][e] *= alpha;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lsum[e] *= alpha;
   }
+  const float nm = -m;
+  float pv[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pv[t][e] = fast_exp2(fmaf(s[t][e], c, nm));
 #pragma unroll
   for (int sk = 0; sk < 2; ++sk)
-    pf[sk] = pack8(t2[4 * sk][0], t2[4 * sk][1], t2[4 * sk + 1][0], t2[4 * sk + 1][1], t2[4 * sk + 2][0], t2[4 * sk + 2][1],
-                   t2[4 * sk + 3][0], t2[4 * sk + 3][1]);
+    pf[sk] = pack8(pv[2 * sk][0], pv[2 * sk][1], pv[2 * sk][2], pv[2 * sk][3], pv[2 * sk + 1][0], pv[2 * sk + 1][1],
+                   pv[2 * sk + 1][2], pv[2 * sk + 1][3]);
 }
 
 // One key tile for both 16-query strips of a wave.  MASK = the tile crosses the diagonal.
-// (Issuing both strips' score products before the first softmax, to keep the matrix pipe busy under
-// the VALU work of the same wave, was measured: it costs 27 more registers and gains nothing at
-// three waves per SIMD.)
+// The row sums of P come out of the matrix pipe: lsum[st] += 1^T P^T, one more 16x16x32 product per
+// strip and 32 keys with an all-ones A operand (every accumulator row then holds the sum for the
+// lane's query, of exactly the bf16 values that multiply V).  That replaces 32 VALU additions per
+// strip and tile by 2 matrix instructions.
 template <bool MASK>
 __device__ __forceinline__ void fwd_tile(const char* ks, const char* vs, const bf16x8 (&qf)[2][2], f32x4 (&o)[2][4], float (&m)[2],
-                                         float (&l)[2], int key0, int q0, int lane, float c) {
+                                         f32x4 (&lsum)[2], int key0, int q0, int lane, float c) {
   const int g = lane >> 4, li = lane & 15;
   // K fragments (A operand): row = key 16t + li, d chunk 4*kk + g
   bf16x8 kf[4][2];
@@ -277,8 +302,14 @@ __device__ __forceinline__ void fwd_tile(const char* ks, const char* vs, const b
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[st][kk], s[t], 0, 0, 0);
     }
-    softmax_strip<MASK>(s, o[st], m[st], l[st], pf[st], rel0 + 16 * st, c);
+    softmax_strip<MASK>(s, o[st], lsum[st], m[st], pf[st], rel0 + 16 * st, c);
   }
+  const s16x8 ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_bits);
+#pragma unroll
+  for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) lsum[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[st][sk], lsum[st], 0, 0, 0);
   // O^T += V^T P^T: V fragments are shared by both strips
 #pragma unroll
   for (int td = 0; td < 4; ++td)
@@ -290,12 +321,14 @@ __device__ __forceinline__ void fwd_tile(const char* ks, const char* vs, const b
     }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
-  const int nqb = p.T / BQ;
-  int blk, bh;
-  head_block_of_workgroup(nqb, blk, bh);
-  const int qb = nqb - 1 - blk;  // longest rows first
+#ifdef ATTN_STAMP
+__device__ unsigned long long g_attn_stamps[1 << 12][8];  // diagnostic build: per workgroup {loop cycles, tiles, rt entry, rt exit, life cycles, sync cycles}
+#define STAMP_ARGS , unsigned long long& st_loop, unsigned long long& st_tiles, unsigned long long& st_sync
+#else
+#define STAMP_ARGS
+#endif
+// One block of 128 queries of one (batch, head): the whole former kernel body.
+__device__ __forceinline__ void attn_fwd_block(const AttnParams& p, char* smem, int bh, int qb, int round STAMP_ARGS) {
   const int b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -316,12 +349,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
 
   wait_all_vmem();
 
-  f32x4 o[2][4];
-  float m[2], l[2];
+  f32x4 o[2][4], lsum[2];
+  float m[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
     m[st] = -__builtin_huge_valf();
-    l[st] = 0.f;
+    lsum[st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int td = 0; td < 4; ++td) o[st][td] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -347,30 +380,49 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
       src[i] += tile_step;
     }
   };
+  __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
   request(0);
   if (n_tiles > 1) request(1);
+#ifdef ATTN_STAMP
+  const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
 
   int stage = 0;
   for (int jt = 0; jt < n_tiles; ++jt) {
+#ifdef ATTN_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long ta = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    take_turns(jt + round);
     if (jt + 1 < n_tiles) wait_vmem_at_most<4>();  // this wave's pieces of tile jt have landed
     else wait_vmem_at_most<0>();
     __syncthreads();  // every wave's pieces are visible; nobody still reads the stage requested next
+#ifdef ATTN_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    st_sync += __builtin_amdgcn_s_memtime() - ta;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (jt + 2 < n_tiles) request(stage == 0 ? 2 : stage - 1);
     const char* ks = smem + stage * 2 * kTileBytes;
     const char* vs = ks + kTileBytes;
     const int key0 = jt * BKV;
     if (key0 <= q0 + 31) {  // otherwise every key of the tile is in this wave's future
-      if (key0 + BKV - 1 > q0) fwd_tile<true>(ks, vs, qf, o, m, l, key0, q0, lane, p.scale_log2);
-      else fwd_tile<false>(ks, vs, qf, o, m, l, key0, q0, lane, p.scale_log2);
+      if (key0 + BKV - 1 > q0) fwd_tile<true>(ks, vs, qf, o, m, lsum, key0, q0, lane, p.scale_log2);
+      else fwd_tile<false>(ks, vs, qf, o, m, lsum, key0, q0, lane, p.scale_log2);
     }
     stage = stage == 2 ? 0 : stage + 1;
   }
+#ifdef ATTN_STAMP
+  st_loop += __builtin_amdgcn_s_memtime() - t_loop0;
+  st_tiles += n_tiles;
+#endif
 
   // Normalise and store.  Lane: query li of strip st, d = 16*td + 4*g + e.
   float inv[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    const float lt = groups_sum(l[st]);
+    const float lt = lsum[st][0];  // every accumulator row holds the full sum over keys for this lane's query
     inv[st] = 1.f / lt;
     const int qi = q0 + 16 * st + li;
     if (g == 0) p.lse[(static_cast<long long>(b) * p.H + h) * p.T + qi] = (m[st] + log2f(lt)) * 0.6931471805599453f;
@@ -379,6 +431,32 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
   const long long o_stride = static_cast<long long>(p.H) * HD;
   store_rows_staged(smem + wid * kOutStripBytes, o, inv, p.o + (static_cast<long long>(b) * p.T + q0) * o_stride + static_cast<long long>(h) * HD,
                     o_stride, lane);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
+  const int round = dispatch_round(p.per_cu);
+  const int nqb = p.T / BQ, per_head = (nqb + 1) >> 1, n_items = per_head * p.B * p.H;
+#ifdef ATTN_STAMP
+  unsigned long long st_loop = 0, st_tiles = 0, st_sync = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+#define STAMP_PASS , st_loop, st_tiles, st_sync
+#else
+#define STAMP_PASS
+#endif
+  for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    int pair, bh;
+    item_of_index(idx, n_items, per_head, pair, bh);
+    const int hi = nqb - 1 - pair;
+    for (int half = 0; half < (pair != hi ? 2 : 1); ++half)  // the long block of the pair, then its short partner
+      attn_fwd_block(p, smem, bh, half == 0 ? hi : pair, round STAMP_PASS);
+  }
+#ifdef ATTN_STAMP
+  if (threadIdx.x == 64 * 3 && blockIdx.x < (1 << 12)) {
+    unsigned long long* r = g_attn_stamps[blockIdx.x];
+    r[0] = st_loop; r[1] = st_tiles; r[2] = rt0; r[3] = __builtin_amdgcn_s_memrealtime(); r[4] = __builtin_amdgcn_s_memtime() - c0; r[5] = st_sync;
+  }
+#endif
 }
 
 
@@ -414,6 +492,7 @@ struct AttnBwdParams {
   long long row_stride, grad_row_stride;
   int B, H, T;
   float scale, scale_log2;
+  int per_cu_dq, per_cu_dkdv;  // resident workgroups per CU of the two launches (priority balancing)
 };
 
 // Row fragment (A operand: row = tile row 16*t + li, k = 32*kk + 8*g ..) of a [rows][64] tile in the v_off image.
@@ -472,12 +551,7 @@ __device__ __forceinline__ void dq_tile(const char* ks, const char* vs, const bf
     }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
-  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
-  const int nqb = p.T / BQ;
-  int blk, bh;
-  head_block_of_workgroup(nqb, blk, bh);
-  const int qb = nqb - 1 - blk;
+__device__ __forceinline__ void attn_bwd_dq_block(const AttnBwdParams& p, char* smem, int bh, int qb, int round) {
   const int b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -538,10 +612,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams 
       src[i] += tile_step;
     }
   };
+  __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
   request(0);
   if (n_tiles > 1) request(1);
   int stage = 0;
   for (int jt = 0; jt < n_tiles; ++jt) {
+    take_turns(jt + round);
     if (jt + 1 < n_tiles) wait_vmem_at_most<4>();
     else wait_vmem_at_most<0>();
     __syncthreads();
@@ -561,6 +637,18 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams 
   float* bq = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + q0) >> 5) * C3 + static_cast<long long>(h) * HD : nullptr;
   store_rows_staged(smem + wid * kOutStripBytes, dq, one,
                     p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD, p.grad_row_stride, lane, bq);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
+  const int round = dispatch_round(p.per_cu_dq);
+  const int nqb = p.T / BQ, per_head = (nqb + 1) >> 1, n_items = per_head * p.B * p.H;
+  for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    int pair, bh;
+    item_of_index(idx, n_items, per_head, pair, bh);
+    const int hi = nqb - 1 - pair;
+    for (int half = 0; half < (pair != hi ? 2 : 1); ++half) attn_bwd_dq_block(p, smem, bh, half == 0 ? hi : pair, round);
+  }
 }
 
 constexpr int BQT = 64;                          // queries per LDS stage in the dK/dV kernel (two 32-query halves)
@@ -636,10 +724,8 @@ __device__ __forceinline__ void dkdv_tile(const char* qs_, const char* dos_, con
   }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParams p) {
-  __shared__ __attribute__((aligned(1024))) char smem[3 * kQStageBytes];  // [3 stages][Q | dO | lse2 | delta]
-  int jb, bh;  // key block; block 0 has the most query tiles and starts first
-  head_block_of_workgroup(p.T / BQ, jb, bh);
+// One block of 128 keys of one (batch, head); key block 0 has the most query tiles.
+__device__ __forceinline__ void attn_bwd_dkdv_block(const AttnBwdParams& p, char* smem, int bh, int jb, int round) {
   const int b = bh / p.H, h = bh % p.H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -703,10 +789,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParam
     }
   };
   const int n_iter = n_qt - first_qt;
+  __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
   request(0);
   if (n_iter > 1) request(1);
   int stage = 0;
   for (int it = 0; it < n_iter; ++it) {
+    take_turns(it + round);
     if (it + 1 < n_iter) {  // leave the next stage's requests in flight: 5 per wave with statistics, else 4
       if (moves_stat) wait_vmem_at_most<5>();
       else wait_vmem_at_most<4>();
@@ -739,6 +827,45 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParam
   store_rows_staged(smem + wid * kOutStripBytes, dv, one, p.dv + out_off, p.grad_row_stride, lane, bvp);
 }
 
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[3 * kQStageBytes];  // [3 stages][Q | dO | lse2 | delta]
+  const int round = dispatch_round(p.per_cu_dkdv);
+  const int nkb = p.T / BQ, per_head = (nkb + 1) >> 1, n_items = per_head * p.B * p.H;
+  for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    int pair, bh;
+    item_of_index(idx, n_items, per_head, pair, bh);
+    const int lo = nkb - 1 - pair;
+    // key block `pair` sees the most queries, its partner the fewest
+    for (int half = 0; half < (pair != lo ? 2 : 1); ++half) attn_bwd_dkdv_block(p, smem, bh, half == 0 ? pair : lo, round);
+  }
+}
+
+}  // namespace
+
+namespace {
+// Workgroups of a persistent launch: exactly as many as are resident at once for this kernel (asked of
+// the runtime, so register or LDS growth cannot silently turn one round into one and a bit), capped by
+// the number of work items, and a multiple of 8 so that the items a workgroup strides over all belong
+// to its own XCD's run.
+template <typename Kernel>
+int resident_per_cu(Kernel kernel) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  return per_cu;
+}
+unsigned persistent_grid(int per_cu, int T, int B, int H) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const long long items = static_cast<long long>((T / BQ + 1) / 2) * B * H;
+  long long g = static_cast<long long>(cus) * per_cu;
+  if (g > items) g = items;
+  g = g >= 8 ? g / 8 * 8 : g;
+  return static_cast<unsigned>(g < 1 ? 1 : g);
+}
 }  // namespace
 
 bool attention_supported(long long T, long long head_dim, long long row_stride) {
@@ -756,7 +883,9 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
   p.row_stride = row_stride;
   p.B = B; p.H = H; p.T = T;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(static_cast<unsigned>(T / BQ) * static_cast<unsigned>(B * H)), dim3(kThreads), 0, stream, p);
+  static const int fwd_per_cu = resident_per_cu(attn_fwd_kernel);
+  p.per_cu = fwd_per_cu;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(persistent_grid(fwd_per_cu, T, B, H)), dim3(kThreads), 0, stream, p);
 }
 
 void launch_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
@@ -781,8 +910,11 @@ void launch_attention_bwd(const void* q, const void* k, const void* v, const voi
   p.scale = softmax_scale;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
   // dQ first: it also produces delta, which the dK/dV kernel consumes
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(static_cast<unsigned>(T / BQ) * static_cast<unsigned>(B * H)), dim3(kThreads), 0, stream, p);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(static_cast<unsigned>(T / BQ) * static_cast<unsigned>(B * H)), dim3(kThreads), 0, stream, p);
+  static const int dq_per_cu = resident_per_cu(attn_bwd_dq_kernel), dkdv_per_cu = resident_per_cu(attn_bwd_dkdv_kernel);
+  p.per_cu_dq = dq_per_cu;
+  p.per_cu_dkdv = dkdv_per_cu;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(persistent_grid(dq_per_cu, T, B, H)), dim3(kThreads), 0, stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(persistent_grid(dkdv_per_cu, T, B, H)), dim3(kThreads), 0, stream, p);
 }
 
 }  // namespace kernels

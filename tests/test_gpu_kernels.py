@@ -491,7 +491,9 @@ def test_flash_attention_forward_backward(B, T, H):
     assert C().attention_supported(T, 64, 3 * Cd)
     o, lse = C().attention_forward(qkv, H, scale)
     (q, k, v), ref_o, ref_lse = _attention_reference(qkv, H, scale)
-    torch.testing.assert_close(lse, ref_lse, rtol=1e-4, atol=1e-4)
+    # the row sums are taken over the bf16-rounded probabilities (the values that multiply V), by the
+    # matrix pipe: the log-sum-exp carries that rounding, at most 2^-9 relative on the sum
+    torch.testing.assert_close(lse, ref_lse, rtol=0, atol=4e-3)
     torch.testing.assert_close(o.float(), ref_o, rtol=2e-2, atol=2e-2)
     go = torch.randn_like(o)
     dqkv, _ = C().attention_backward(go, qkv, o, lse, H, scale)

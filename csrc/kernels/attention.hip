@@ -433,7 +433,10 @@ __device__ __forceinline__ void attn_fwd_block(const AttnParams& p, char* smem, 
                     o_stride, lane);
 }
 
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
+#ifndef ATTN_FWD_WGS
+#define ATTN_FWD_WGS 2
+#endif
+__global__ __launch_bounds__(kThreads, ATTN_FWD_WGS) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
   const int round = dispatch_round(p.per_cu);
   const int nqb = p.T / BQ, per_head = (nqb + 1) >> 1, n_items = per_head * p.B * p.H;
@@ -534,7 +537,7 @@ __device__ __forceinline__ void dq_tile(const char* ks, const char* vs, const bf
       for (int e = 0; e < 4; ++e) {
         float pe = fast_exp2(fmaf(s[t][e], c, -lse2[st]));
         if (MASK && (16 * t + e > rel)) pe = 0.f;
-        s[t][e] = pe * (dp[t][e] - dl[st]) * scale;
+        s[t][e] = pe * (dp[t][e] - dl[st]);  // the softmax scale is applied once, to the finished dQ rows
       }
 #pragma unroll
     for (int sk = 0; sk < 2; ++sk)
@@ -632,10 +635,10 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnBwdParams& p, char* 
     stage = stage == 2 ? 0 : stage + 1;
   }
   __syncthreads();  // tile stages -> output strips
-  const float one[2] = {1.f, 1.f};
+  const float by_scale[2] = {p.scale, p.scale};
   const long long C3 = 3LL * p.H * HD;
   float* bq = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + q0) >> 5) * C3 + static_cast<long long>(h) * HD : nullptr;
-  store_rows_staged(smem + wid * kOutStripBytes, dq, one,
+  store_rows_staged(smem + wid * kOutStripBytes, dq, by_scale,
                     p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD, p.grad_row_stride, lane, bq);
 }
 
@@ -706,7 +709,7 @@ __device__ __forceinline__ void dkdv_tile(const char* qs_, const char* dos_, con
         float pe = fast_exp2(fmaf(s[qs][e], c, -l2[qs][e]));
         if (MASK && (16 * qs + e < rel)) pe = 0.f;
         pv[qs][e] = pe;
-        dsv[qs][e] = pe * (dp[qs][e] - dl[qs][e]) * scale;
+        dsv[qs][e] = pe * (dp[qs][e] - dl[qs][e]);  // the softmax scale is applied once, to the finished dK rows
       }
     pB[kt2] = pack8(pv[0][0], pv[0][1], pv[0][2], pv[0][3], pv[1][0], pv[1][1], pv[1][2], pv[1][3]);
     dsB[kt2] = pack8(dsv[0][0], dsv[0][1], dsv[0][2], dsv[0][3], dsv[1][0], dsv[1][1], dsv[1][2], dsv[1][3]);
@@ -823,7 +826,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_block(const AttnBwdParams& p, char
   const long long C3 = 3LL * p.H * HD;
   float* bk = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + k0w) >> 5) * C3 + (p.H + h) * static_cast<long long>(HD) : nullptr;
   float* bvp = bk ? bk + static_cast<long long>(p.H) * HD : nullptr;
-  store_rows_staged(smem + wid * kOutStripBytes, dk, one, p.dk + out_off, p.grad_row_stride, lane, bk);
+  const float by_scale[2] = {p.scale, p.scale};
+  store_rows_staged(smem + wid * kOutStripBytes, dk, by_scale, p.dk + out_off, p.grad_row_stride, lane, bk);
   store_rows_staged(smem + wid * kOutStripBytes, dv, one, p.dv + out_off, p.grad_row_stride, lane, bvp);
 }
 

@@ -55,8 +55,15 @@ class FusedAdamW(Optimizer):
         super().__init__(params, defaults)
         self.master_weights = bool(master_weights)
         self.max_grad_norm = max_grad_norm
-        self._hparams: Dict[int, torch.Tensor] = {}       # group index -> device float32[8]
-        self._hparams_host: Dict[int, tuple] = {}
+        # Device-side hyper-parameters + step counter, one float32[8] per (group, cohort).  A cohort is the set
+        # of a group's parameters that share a step count; its key is the group's tick count minus that step
+        # count, which stays constant for a parameter's whole life: 0 for parameters updated from the first
+        # step on, -n for parameters restored at step n, +k for a parameter that got its first gradient after
+        # k steps.  Almost always there is exactly one cohort per group.
+        self._hparams: Dict[tuple, torch.Tensor] = {}
+        self._hparams_host: Dict[tuple, tuple] = {}
+        self._ticks: Dict[int, int] = {}                  # group index -> updates applied to the group so far
+        self._step_i: Dict[torch.Tensor, int] = {}        # parameter -> its step count as a python int
         self._clip: Optional[Dict[str, torch.Tensor]] = None
         self.last_grad_norm: Optional[torch.Tensor] = None
 
@@ -71,19 +78,48 @@ class FusedAdamW(Optimizer):
                 st["master"] = p.detach().to(torch.float32).clone()
         return st
 
-    def _device_hparams(self, gi: int, group: dict, device: torch.device, step_before: int) -> torch.Tensor:
-        host = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"])
-        hp = self._hparams.get(gi)
+    @staticmethod
+    def _host_hparams(group: dict) -> tuple:
+        return (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"])
+
+    def _device_hparams(self, key: tuple, group: dict, device: torch.device, step_before: int) -> torch.Tensor:
+        host = self._host_hparams(group)
+        hp = self._hparams.get(key)
         if hp is None or hp.device != device:
             vals = torch.tensor(list(host) + [0.0, 0.0, 0.0], dtype=torch.float32)
             vals[5] = torch.tensor(step_before, dtype=torch.int32).view(torch.float32)
             hp = vals.to(device)
-            self._hparams[gi] = hp
-            self._hparams_host[gi] = host
-        elif self._hparams_host[gi] != host:
+            self._hparams[key] = hp
+            self._hparams_host[key] = host
+        elif self._hparams_host[key] != host:
             hp[:5].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)
-            self._hparams_host[gi] = host
+            self._hparams_host[key] = host
         return hp
+
+    def sync_hparams(self) -> None:
+        """Copies changed ``param_groups`` hyper-parameters (a learning-rate schedule) to the device.  ``step()``
+        does this itself; a captured graph that replays the update without calling ``step()`` must call it
+        before each replay (``GraphedStep`` does)."""
+        for (gi, origin), hp in self._hparams.items():
+            host = self._host_hparams(self.param_groups[gi])
+            if self._hparams_host[(gi, origin)] != host:
+                hp[:5].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)
+                self._hparams_host[(gi, origin)] = host
+
+    def note_external_steps(self, n: int = 1) -> None:
+        """Advances the host-side step mirrors by ``n`` updates that ran on the device without ``step()``
+        (graph replays), so that ``state_dict()`` reports the true step counts."""
+        for gi, group in enumerate(self.param_groups):
+            touched = False
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    st["step"] += n
+                    if p in self._step_i:
+                        self._step_i[p] += n
+                    touched = True
+            if touched:
+                self._ticks[gi] = self._ticks.get(gi, 0) + n
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -113,24 +149,32 @@ class FusedAdamW(Optimizer):
             grad_scale = self._clip_coefficient(C, [p.grad for _, _, ps in gpu_groups for p in ps])
         for gi, group, ps in gpu_groups:
             states = [self._init_state(p) for p in ps]
-            step_before = int(states[0]["step"].item()) if gi not in self._hparams else 0
-            hp = self._device_hparams(gi, group, ps[0].device, step_before)
-            C.adamw_tick(hp)
-            pv, gv, mv, vv, wv = [], [], [], [], []
+            ticks = self._ticks.get(gi, 0)
+            cohorts: Dict[int, list] = {}
             for p, st in zip(ps, states):
-                g = p.grad
-                if not _is_dense(p):
-                    raise RuntimeError("FusedAdamW: parameters must be dense (contiguous in some memory format)")
-                if g.stride() != p.stride():
-                    g = torch.empty_like(p).copy_(g)  # bring the gradient into the parameter's element order
-                pv.append(_flat_dense(p))
-                gv.append(_flat_dense(g))
-                mv.append(_flat_dense(st["exp_avg"]))
-                vv.append(_flat_dense(st["exp_avg_sq"]))
-                wv.append(_flat_dense(st["master"]) if "master" in st else None)
-            C.adamw_step(pv, gv, mv, vv, wv, hp, grad_scale)
-            for s in states:
-                s["step"] += 1
+                if p not in self._step_i:
+                    self._step_i[p] = int(st["step"].item())  # restored or fresh; read once, then mirrored as an int
+                cohorts.setdefault(ticks - self._step_i[p], []).append((p, st))
+            for origin, members in cohorts.items():
+                hp = self._device_hparams((gi, origin), group, ps[0].device, ticks - origin)
+                C.adamw_tick(hp)
+                pv, gv, mv, vv, wv = [], [], [], [], []
+                for p, st in members:
+                    g = p.grad
+                    if not _is_dense(p):
+                        raise RuntimeError("FusedAdamW: parameters must be dense (contiguous in some memory format)")
+                    if g.stride() != p.stride():
+                        g = torch.empty_like(p).copy_(g)  # bring the gradient into the parameter's element order
+                    pv.append(_flat_dense(p))
+                    gv.append(_flat_dense(g))
+                    mv.append(_flat_dense(st["exp_avg"]))
+                    vv.append(_flat_dense(st["exp_avg_sq"]))
+                    wv.append(_flat_dense(st["master"]) if "master" in st else None)
+                C.adamw_step(pv, gv, mv, vv, wv, hp, grad_scale)
+                for p, st in members:
+                    st["step"] += 1
+                    self._step_i[p] += 1
+            self._ticks[gi] = ticks + 1
         return loss
 
     def _clip_coefficient(self, C, grads: List[torch.Tensor]) -> torch.Tensor:
@@ -173,6 +217,8 @@ class FusedAdamW(Optimizer):
         # Device-side step counters are rebuilt from the restored per-parameter steps.
         self._hparams.clear()
         self._hparams_host.clear()
+        self._ticks.clear()
+        self._step_i.clear()
         for st in self.state.values():
             if "step" in st and torch.is_tensor(st["step"]):
                 st["step"] = st["step"].detach().to("cpu", torch.float32)

@@ -87,7 +87,8 @@ class _ProjectionXent(torch.autograd.Function):
 
 
 def projection_cross_entropy(x: torch.Tensor, weight: torch.Tensor, targets: torch.Tensor, reduction: str = "mean",
-                             ignore_index: int = -100, n_classes: Optional[int] = None, impl: str = "native") -> XentResult:
+                             ignore_index: int = -100, n_classes: Optional[int] = None, impl: str = "native",
+                             check_targets: Optional[bool] = None) -> XentResult:
     """Cross-entropy of ``x @ weight.T`` (``x``: [..., K], ``weight``: [C, K]) against ``targets``.
 
     On the GPU the logits exist only inside the op: they are written by the GEMM, turned into
@@ -99,16 +100,36 @@ def projection_cross_entropy(x: torch.Tensor, weight: torch.Tensor, targets: tor
     x2 = x.reshape(-1, x.shape[-1])
     t1 = targets.reshape(-1)
     nc = weight.shape[0] if n_classes is None else int(n_classes)
+    if _want_target_check(check_targets):
+        check_targets_in_range(t1, nc, ignore_index)
     fused_ok = (x2.is_cuda and x2.dtype == weight.dtype and x2.dtype in (torch.float32, torch.bfloat16, torch.float16)
                 and nc > 64 and _ext.have_C())
     if not fused_ok:
-        return softmax_cross_entropy(F.linear(x2, weight), t1, reduction, ignore_index, nc, inplace_backward=True)
+        return softmax_cross_entropy(F.linear(x2, weight), t1, reduction, ignore_index, nc, inplace_backward=True, check_targets=False)
     loss, correct, metrics = _ProjectionXent.apply(x2.contiguous(), weight, t1.contiguous(), reduction, ignore_index, nc, impl)
     return XentResult(loss, correct, metrics)
 
 
+def check_targets_in_range(targets: torch.Tensor, n_classes: int, ignore_index: int) -> None:
+    """Raises ``IndexError`` when a target is neither a class index nor ``ignore_index`` (what
+    ``nn.CrossEntropyLoss`` reports through a device-side assert).  Costs a host synchronisation, so the
+    loss functions only run it when asked (``check_targets=True`` or ``DIST_CHECK_TARGETS=1``); without
+    the check the kernels treat such a row like an ignored one."""
+    bad = (targets != ignore_index) & ((targets < 0) | (targets >= n_classes))
+    if bool(bad.any()):
+        v = int(targets[bad][0])
+        raise IndexError(f"Target {v} is out of bounds (classes 0..{n_classes - 1}, ignore_index {ignore_index})")
+
+
+def _want_target_check(flag: Optional[bool]) -> bool:
+    import os
+
+    return bool(flag) if flag is not None else os.environ.get("DIST_CHECK_TARGETS", "0") == "1"
+
+
 def softmax_cross_entropy(logits: torch.Tensor, targets: torch.Tensor, reduction: str = "mean", ignore_index: int = -100,
-                          n_classes: Optional[int] = None, inplace_backward: bool = False) -> XentResult:
+                          n_classes: Optional[int] = None, inplace_backward: bool = False,
+                          check_targets: Optional[bool] = None) -> XentResult:
     """Cross-entropy of ``logits[N, C]`` against class indices ``targets[N]``.
 
     ``n_classes`` < C marks trailing columns as padding (a vocabulary padded for aligned
@@ -122,6 +143,8 @@ def softmax_cross_entropy(logits: torch.Tensor, targets: torch.Tensor, reduction
         raise ValueError("softmax_cross_entropy expects logits of shape [N, C]")
     C_ = logits.shape[1]
     nc = C_ if n_classes is None else int(n_classes)
+    if _want_target_check(check_targets):
+        check_targets_in_range(targets, nc, ignore_index)
     if not logits.is_cuda:
         lg = logits[:, :nc] if nc != C_ else logits
         row = F.cross_entropy(lg.float(), targets, reduction="none", ignore_index=ignore_index)
@@ -142,8 +165,9 @@ class SoftmaxCrossEntropy(nn.Module):
     ``last_correct`` / ``last_metrics`` hold the accuracy by-products of the same pass."""
 
     def __init__(self, reduction: str = "mean", ignore_index: int = -100, n_classes: Optional[int] = None,
-                 inplace_backward: bool = False):
+                 inplace_backward: bool = False, check_targets: Optional[bool] = None):
         super().__init__()
+        self.check_targets = check_targets
         self.reduction = reduction
         self.ignore_index = ignore_index
         self.n_classes = n_classes
@@ -155,6 +179,7 @@ class SoftmaxCrossEntropy(nn.Module):
         if logits.dim() > 2:
             logits = logits.reshape(-1, logits.shape[-1])
             targets = targets.reshape(-1)
-        r = softmax_cross_entropy(logits, targets, self.reduction, self.ignore_index, self.n_classes, self.inplace_backward)
+        r = softmax_cross_entropy(logits, targets, self.reduction, self.ignore_index, self.n_classes, self.inplace_backward,
+                                  self.check_targets)
         self.last_correct, self.last_metrics = r.correct, r.metrics
         return r.loss

@@ -49,6 +49,15 @@ class GraphedStep:
         return loss.detach()
 
     def step(self) -> torch.Tensor:
+        # The replayed update never passes through optimizer.step(): push changed hyper-parameters (a
+        # learning-rate schedule edits param_groups on the host) to the device first, and keep the
+        # optimizer's host-side step mirrors in line with the device counters afterwards.
+        sync = getattr(self.optimizer, "sync_hparams", None)
+        if sync is not None:
+            sync()
         self.graph.replay()
         self.replays += 1
+        note = getattr(self.optimizer, "note_external_steps", None)
+        if note is not None:
+            note(1)
         return self.static_loss

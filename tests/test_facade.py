@@ -287,3 +287,19 @@ def test_launcher_leaves_ipc_mode_alone(monkeypatch):
 
     src = inspect.getsource(L.launch)
     assert '"HSA_ENABLE_IPC_MODE_LEGACY":' not in src
+
+
+def test_cross_entropy_target_check_is_opt_in():
+    import torch
+
+    from distributed_pytorch_amd.ops import SoftmaxCrossEntropy, softmax_cross_entropy
+
+    logits = torch.randn(4, 5)
+    bad = torch.tensor([0, 5, 1, 2])
+    with pytest.raises(IndexError, match="Target 5 is out of bounds"):
+        softmax_cross_entropy(logits, bad, check_targets=True)
+    with pytest.raises(IndexError):
+        SoftmaxCrossEntropy(check_targets=True)(logits, torch.tensor([0, -3, 1, 2]))
+    ok = torch.tensor([0, 4, -100, 2])           # ignore_index is not an error
+    ref = torch.nn.functional.cross_entropy(logits, ok)
+    torch.testing.assert_close(softmax_cross_entropy(logits, ok, check_targets=True).loss, ref)

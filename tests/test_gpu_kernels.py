@@ -127,6 +127,50 @@ def test_fused_adamw_clipping():
         torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
 
 
+def test_fused_adamw_late_parameter_restore_and_graph_replay_bookkeeping():
+    """Per-parameter step counts: a parameter that gets its first gradient after others have stepped, a
+    state restored at different steps, and updates replayed from a captured graph all see the bias
+    correction torch's per-parameter counters would give."""
+    from distributed_pytorch_amd.ops import FusedAdamW
+
+    torch.manual_seed(9)
+    ref_p = [torch.randn(64, dtype=torch.float64).requires_grad_(), torch.randn(33, dtype=torch.float64).requires_grad_()]
+    my_p = [p.detach().float().to(DEV).requires_grad_() for p in ref_p]
+    ref, mine = torch.optim.AdamW(ref_p, lr=1e-2), FusedAdamW(my_p, lr=1e-2)
+    for step in range(5):
+        for k, (rp, mp) in enumerate(zip(ref_p, my_p)):
+            if k == 1 and step < 2:       # the second parameter joins at step 2
+                rp.grad, mp.grad = None, None
+                continue
+            g = torch.randn(rp.shape, dtype=torch.float64)
+            rp.grad, mp.grad = g, g.float().to(DEV)
+        ref.step()
+        mine.step()
+    for rp, mp in zip(ref_p, my_p):
+        torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
+    sd = mine.state_dict()
+    assert [int(sd["state"][i]["step"]) for i in (0, 1)] == [5, 3]
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    # restore into a fresh optimizer and keep going: both cohorts continue from their own step
+    mine2 = FusedAdamW(my_p, lr=1e-2)
+    mine2.load_state_dict(sd)
+    for step in range(2):
+        for rp, mp in zip(ref_p, my_p):
+            g = torch.randn(rp.shape, dtype=torch.float64)
+            rp.grad, mp.grad = g, g.float().to(DEV)
+        ref.step()
+        mine2.step()
+    for rp, mp in zip(ref_p, my_p):
+        torch.testing.assert_close(mp.detach().cpu().double(), rp.detach(), rtol=2e-5, atol=2e-6)
+    assert [int(mine2.state_dict()["state"][i]["step"]) for i in (0, 1)] == [7, 5]
+    # graph-replay bookkeeping: hyper-parameters pushed without step(), host mirrors advanced
+    mine2.param_groups[0]["lr"] = 5e-3
+    mine2.sync_hparams()
+    assert all(abs(float(hp[0]) - 5e-3) < 1e-9 for hp in mine2._hparams.values())
+    mine2.note_external_steps(3)
+    assert [int(mine2.state_dict()["state"][i]["step"]) for i in (0, 1)] == [10, 8]
+
+
 def test_grad_norm_is_fixed_order_and_exact():
     """Sum of squares over many tensors (several dtypes, sizes beyond one table): two stages with a
     fixed summation order, so repeated runs are bit-identical, and the value matches fp64."""

@@ -75,15 +75,17 @@ PYBIND11_MODULE(_C, m) {
 
   py::class_<Reducer, std::shared_ptr<Reducer>>(m, "Reducer")
       .def(py::init([](std::vector<at::Tensor> params, std::vector<BucketSpec> buckets, std::shared_ptr<Transport> t,
-                       bool gradient_as_bucket_view, bool unpack_to_grads, int64_t max_collective_bytes) {
+                       bool gradient_as_bucket_view, bool unpack_to_grads, int64_t max_collective_bytes, bool track_unused) {
              ReducerOptions o;
              o.gradient_as_bucket_view = gradient_as_bucket_view;
              o.unpack_to_grads = unpack_to_grads;
              o.max_collective_bytes = max_collective_bytes;
+             o.track_unused = track_unused;
              return std::make_shared<Reducer>(std::move(params), std::move(buckets), std::move(t), o);
            }),
            py::arg("params"), py::arg("buckets"), py::arg("transport"), py::arg("gradient_as_bucket_view") = true,
-           py::arg("unpack_to_grads") = true, py::arg("max_collective_bytes") = 0)
+           py::arg("unpack_to_grads") = true, py::arg("max_collective_bytes") = 0,
+           py::arg("track_unused") = false)
       .def("prepare_for_backward", &Reducer::prepare_for_backward, py::arg("sync") = true)
       .def("armed", &Reducer::armed)
       .def("ready_order", &Reducer::ready_order)
@@ -94,6 +96,7 @@ PYBIND11_MODULE(_C, m) {
       .def("num_collectives", &Reducer::num_collectives)
       .def("launch_positions", &Reducer::launch_positions)
       .def("slices_per_bucket", &Reducer::slices_per_bucket)
+      .def("globally_unused", &Reducer::globally_unused)
       .def("broadcast_parameters", &Reducer::broadcast_parameters, py::arg("root") = 0,
            py::call_guard<py::gil_scoped_release>())
       .def("detach", &Reducer::detach);

@@ -55,6 +55,9 @@ class RcclTransport final : public Transport {
     comm_->all_reduce_async(flat, average ? static_cast<int>(ncclAvg) : static_cast<int>(ncclSum), slot);
   }
   void broadcast(at::Tensor flat, int root) override { comm_->broadcast(flat, root); }
+  void all_reduce_sum_blocking(at::Tensor t) override {
+    comm_->all_reduce(t, static_cast<int>(ncclSum));  // on the current stream; the caller's copy to the host waits for it
+  }
   void wait_all() override { comm_->wait_all_slots(); }
   int world() const override { return comm_->world(); }
 
@@ -78,6 +81,12 @@ class C10dTransport final : public Transport {
     o.rootRank = root;
     pg_->broadcast(ts, o)->wait();
   }
+  void all_reduce_sum_blocking(at::Tensor t) override {
+    std::vector<at::Tensor> ts{t};
+    c10d::AllreduceOptions o;
+    o.reduceOp = c10d::ReduceOp::SUM;
+    pg_->allreduce(ts, o)->wait();
+  }
   void wait_all() override {
     for (auto& w : works_) w->wait();
     works_.clear();
@@ -94,6 +103,7 @@ class LocalTransport final : public Transport {
   bool native_average() const override { return true; }
   void all_reduce_async(at::Tensor, int, bool) override {}
   void broadcast(at::Tensor, int) override {}
+  void all_reduce_sum_blocking(at::Tensor) override {}
   void wait_all() override {}
   int world() const override { return 1; }
 };
@@ -178,6 +188,7 @@ void Reducer::prepare_for_backward(bool sync) {
   next_bucket_ = 0;
   ready_order_.clear();
   launch_pos_.assign(buckets_.size(), -1);
+  had_grad_.assign(params_.size(), 0);
   for (auto& bs : buckets_) {
     bs.pending = static_cast<int64_t>(bs.spec.param_indices.size());
     bs.launched = false;
@@ -269,6 +280,10 @@ void Reducer::unpack_from_bucket(BucketState& bs) {
     at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
     const at::Tensor& g = p.grad();
     if (!g.defined()) {
+      // Unused on every rank (known only with track_unused): grad stays None.
+      if (opt_.track_unused &&
+          std::binary_search(last_globally_unused_.begin(), last_globally_unused_.end(), bs.spec.param_indices[j]))
+        continue;
       // Locally unused parameter: it still receives the globally reduced gradient.
       p.mutable_grad() = bs.views[j].to(p.scalar_type());
       continue;
@@ -291,6 +306,7 @@ void Reducer::launch_bucket(size_t b) {
     at::Tensor& p = params_[static_cast<size_t>(bs.spec.param_indices[j])];
     const at::Tensor& g = p.grad();
     at::Tensor& v = bs.views[j];
+    had_grad_[static_cast<size_t>(bs.spec.param_indices[j])] = g.defined() ? 1 : 0;
     if (!g.defined()) {
       v.zero_();  // no gradient exists locally: this rank contributes zeros
     } else if (g.data_ptr() == v.data_ptr()) {
@@ -329,6 +345,20 @@ void Reducer::finalize_backward() {
   for (size_t b = next_bucket_; b < buckets_.size(); ++b) launch_bucket(b);
   next_bucket_ = buckets_.size();
   transport_->wait_all();
+  last_globally_unused_.clear();
+  if (opt_.track_unused) {
+    // Which parameters got a gradient on at least one rank: sum of the local 0/1 flags.
+    at::Tensor flags = at::empty({static_cast<int64_t>(params_.size())}, at::TensorOptions().dtype(at::kInt));
+    int32_t* fp = flags.data_ptr<int32_t>();
+    for (size_t i = 0; i < params_.size(); ++i) fp[i] = had_grad_[i];
+    const at::Device dev = buckets_.empty() ? at::Device(at::kCPU) : buckets_[0].spec.buffer.device();
+    at::Tensor on_dev = dev.is_cpu() ? flags : flags.to(dev);
+    transport_->all_reduce_sum_blocking(on_dev);
+    at::Tensor back = on_dev.is_cpu() ? on_dev : on_dev.cpu();
+    const int32_t* bp = back.data_ptr<int32_t>();
+    for (size_t i = 0; i < params_.size(); ++i)
+      if (locator_[i].first >= 0 && bp[i] == 0) last_globally_unused_.push_back(static_cast<int64_t>(i));
+  }
   if (opt_.unpack_to_grads)
     for (auto& bs : buckets_) unpack_from_bucket(bs);
   armed_ = false;

@@ -36,6 +36,8 @@ class Transport {
   virtual bool native_average() const = 0;
   virtual void all_reduce_async(at::Tensor flat, int slot, bool average) = 0;
   virtual void broadcast(at::Tensor flat, int root) = 0;
+  // Blocking sum all-reduce of a small tensor (the "gradient used anywhere" bitmap).
+  virtual void all_reduce_sum_blocking(at::Tensor t) = 0;
   // Make the consumer of the buckets (current stream / host thread) wait for all pending ops.
   virtual void wait_all() = 0;
   virtual int world() const = 0;
@@ -61,6 +63,11 @@ struct ReducerOptions {
   // table, an 8192x8192 layer) from being one monolithic operation: each slice has its own
   // completion event, and on the host-side (gloo) transport the slices run concurrently.
   int64_t max_collective_bytes = 0;
+  // find_unused_parameters: after each synchronised backward the ranks agree (one small all-reduce and a
+  // device-to-host copy, as in torch's reducer) on which parameters produced a gradient on ANY rank; a
+  // parameter unused everywhere keeps grad = None instead of receiving zeros, so an optimizer with weight
+  // decay or momentum leaves it alone.
+  bool track_unused = false;
 };
 
 class Reducer {
@@ -86,6 +93,8 @@ class Reducer {
   std::vector<int64_t> launch_positions() const { return last_launch_pos_; }
   // Per bucket: number of all-reduce slices.
   std::vector<int64_t> slices_per_bucket() const;
+  // Parameters that no rank produced a gradient for in the last synchronised backward (track_unused only).
+  std::vector<int64_t> globally_unused() const { return last_globally_unused_; }
   // Broadcast every bucket-ordered parameter from `root` (initial parameter sync).
   void broadcast_parameters(int root);
   // Removes the autograd hooks (also done by the destructor).
@@ -124,7 +133,8 @@ class Reducer {
   bool callback_queued_ = false;
   size_t next_bucket_ = 0;
   std::vector<int64_t> ready_order_, last_ready_order_;
-  std::vector<int64_t> launch_pos_, last_launch_pos_;
+  std::vector<int64_t> launch_pos_, last_launch_pos_, last_globally_unused_;
+  std::vector<char> had_grad_;  // per parameter: a gradient existed locally when its bucket was launched
   int64_t n_syncs_ = 0, n_launches_ = 0, n_pack_launches_ = 0, n_collectives_ = 0;
 };
 

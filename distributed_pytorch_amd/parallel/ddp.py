@@ -89,7 +89,9 @@ class DistributedDataParallel(nn.Module):
         self.module = module
         self.device_ids = device_ids  # accepted for API compatibility; the module's own device is used
         self.broadcast_buffers = bool(broadcast_buffers)
-        self.find_unused_parameters = bool(find_unused_parameters)  # unused params are always tolerated
+        # Unused parameters are always tolerated; with find_unused_parameters=True the ranks also agree on which
+        # parameters were unused EVERYWHERE, and those keep grad = None (torch's behaviour) instead of zeros.
+        self.find_unused_parameters = bool(find_unused_parameters)
         self.require_backward_grad_sync = True
 
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
@@ -190,7 +192,7 @@ class DistributedDataParallel(nn.Module):
         self._bucket_buffers = [s.buffer for s in specs]
         self._bucket_params = [list(b.param_indices) for b in plan.buckets]
         self._reducer = self._C.Reducer(self._params, specs, self._transport, self._grad_as_view, True,
-                                        int(self._max_collective_bytes))
+                                        int(self._max_collective_bytes), self.find_unused_parameters and self.world_size > 1)
 
     def _agreed_ready_order(self) -> List[int]:
         """Rank 0's observed gradient-ready order, on every rank (the layouts must be identical)."""

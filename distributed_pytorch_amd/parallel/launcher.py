@@ -116,6 +116,95 @@ def cpu_slices(nprocs: int) -> List[List[int]]:
     return [cpus[r * per:(r + 1) * per] for r in range(nprocs)]
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def gpu_numa_nodes(root: str = "/") -> List[int]:
+    """NUMA node of every GPU in HIP's enumeration order (the KFD topology's GPU nodes, in node order),
+    read from sysfs only -- the launcher parent must not initialise the GPU runtime.  -1 = unknown."""
+    base = os.path.join(root, "sys/class/kfd/kfd/topology/nodes")
+    try:
+        ids = sorted(int(d) for d in os.listdir(base) if d.isdigit())
+    except OSError:
+        return []
+    out = []
+    for i in ids:
+        props = {}
+        try:
+            with open(os.path.join(base, str(i), "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue  # a CPU node
+        node = -1
+        try:
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            addr = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+            with open(os.path.join(root, "sys/bus/pci/devices", addr, "numa_node")) as f:
+                node = int(f.read().strip())
+        except (OSError, ValueError):
+            node = -1
+        out.append(node)
+    return out
+
+
+def numa_cpu_slices(rank_gpus: Sequence[int], gpu_nodes: Sequence[int], node_cpus: Dict[int, List[int]],
+                    affinity: Sequence[int]) -> Optional[List[List[int]]]:
+    """CPU slice per rank taken from the NUMA node its GPU hangs off: the ranks of one node split that
+    node's allowed CPUs evenly, in rank order.  ``rank_gpus[r]`` is the physical GPU index of rank r.
+    Returns None when the topology is unknown for any rank (the caller falls back to equal contiguous
+    slices), or when a node has fewer allowed CPUs than ranks."""
+    allowed = set(affinity)
+    by_node: Dict[int, List[int]] = {}
+    for r, g in enumerate(rank_gpus):
+        if g < 0 or g >= len(gpu_nodes) or gpu_nodes[g] < 0 or gpu_nodes[g] not in node_cpus:
+            return None
+        by_node.setdefault(gpu_nodes[g], []).append(r)
+    out: List[List[int]] = [[] for _ in rank_gpus]
+    for node, ranks in by_node.items():
+        cpus = [c for c in node_cpus[node] if c in allowed]
+        per = len(cpus) // len(ranks)
+        if per < 1:
+            return None
+        for k, r in enumerate(ranks):
+            out[r] = cpus[k * per:(k + 1) * per]
+    return out
+
+
+def topology_cpu_slices(rank_gpu_ids: Sequence[str], root: str = "/") -> Optional[List[List[int]]]:
+    """``numa_cpu_slices`` fed from sysfs; ``rank_gpu_ids`` are the visibility-variable entries of the ranks'
+    GPUs (numeric indices only; UUID-style entries give None)."""
+    try:
+        gpus = [int(g) for g in rank_gpu_ids]
+        affinity = sorted(os.sched_getaffinity(0))
+    except (ValueError, AttributeError):
+        return None
+    nodes = gpu_numa_nodes(root)
+    if not nodes:
+        return None
+    node_cpus: Dict[int, List[int]] = {}
+    for n in set(nodes):
+        try:
+            with open(os.path.join(root, f"sys/devices/system/node/node{n}/cpulist")) as f:
+                node_cpus[n] = _parse_cpulist(f.read())
+        except OSError:
+            pass
+    return numa_cpu_slices(gpus, nodes, node_cpus, affinity)
+
+
 # --------------------------------------------------------------------------- child side
 def _set_pdeathsig() -> None:
     try:
@@ -243,7 +332,8 @@ class ProcessContext:
         raise ProcessExitedException(f"process {failed} terminated with exit code {code}", failed, p.pid, code)
 
 
-def spawn(worker_fn: Callable, args: tuple = (), nprocs: int = 1, *, env_per_rank: Optional[List[Dict[str, Optional[str]]]] = None, pin_cpus: bool = True, join: bool = True, monitor=None):
+def spawn(worker_fn: Callable, args: tuple = (), nprocs: int = 1, *, env_per_rank: Optional[List[Dict[str, Optional[str]]]] = None, pin_cpus: bool = True, join: bool = True, monitor=None,
+          cpu_sets: Optional[List[List[int]]] = None):
     """Start ``nprocs`` fresh interpreters running ``worker_fn(rank, *args)``.
 
     ``worker_fn`` must be importable from the child (module-level function) and the
@@ -251,7 +341,8 @@ def spawn(worker_fn: Callable, args: tuple = (), nprocs: int = 1, *, env_per_ran
     spawn start method the reference relies on (reference min_DDP.py:133-139).
     """
     ctx = mp.get_context("spawn")
-    slices = cpu_slices(nprocs) if pin_cpus else [[] for _ in range(nprocs)]
+    # cpu_sets: one CPU list per rank chosen by the caller (NUMA-local to the rank's GPU); else equal contiguous slices
+    slices = (cpu_sets if cpu_sets is not None else cpu_slices(nprocs)) if pin_cpus else [[] for _ in range(nprocs)]
     procs, conns = [], []
     parent_pid = os.getpid()
     for rank in range(nprocs):
@@ -359,8 +450,11 @@ def launch(worker_fn: Callable, *args, nprocs: Optional[int] = None):
                 e.update(common)
             from .heartbeat import HangMonitor
 
+            cpu_sets = None
+            if use_gpu and world_size <= len(ids):
+                cpu_sets = topology_cpu_slices(ids[:world_size])  # CPUs next to each rank's GPU, when sysfs tells
             spawn(worker_fn, args=(world_size, *args), nprocs=world_size, env_per_rank=env_per_rank, pin_cpus=os.environ.get("DIST_CPU_AFFINITY", "1") != "0", join=True,
-                  monitor=HangMonitor(store, world_size))
+                  monitor=HangMonitor(store, world_size), cpu_sets=cpu_sets)
         finally:
             store.close()
     elif world_size == 1:

@@ -244,3 +244,42 @@ def hang_worker(rank, world_size, out_dir):
         time.sleep(120)         # "hung": never reaches collective #2
     dist.all_reduce(t)
     dist.cleanup()
+
+
+class _PartlyUsed(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.shared = nn.Linear(4, 4)
+        self.rank0_only = nn.Linear(4, 4)
+        self.never = nn.Linear(4, 4)
+
+    def forward(self, x, use_extra):
+        h = self.shared(x)
+        return self.rank0_only(h) if use_extra else h
+
+
+def ddp_unused_worker(rank, world_size, out_dir):
+    """find_unused_parameters=True: a parameter unused on every rank keeps grad None (and is not touched by a
+    weight-decaying optimizer); one unused on this rank only still receives the averaged gradient."""
+    import distributed as dist
+
+    dist.init_process_group(rank, world_size, "gloo")
+    torch.manual_seed(3)
+    model = dist.prepare_ddp_model(_PartlyUsed(), [rank], find_unused_parameters=True)
+    never_before = model.module.never.weight.detach().clone()
+    opt = torch.optim.AdamW(model.parameters(), 1e-2, weight_decay=0.5)
+    res = {}
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        x = torch.ones(2, 4) * (rank + 1)
+        model(x, use_extra=(rank == 0)).sum().backward()
+        if step == 0:
+            res["never_grad_is_none"] = model.module.never.weight.grad is None and model.module.never.bias.grad is None
+            g = model.module.rank0_only.bias.grad
+            res["rank0_only_bias_grad"] = None if g is None else g.tolist()
+            res["globally_unused"] = sorted(int(i) for i in model.reducer.globally_unused())
+        opt.step()
+    res["never_untouched"] = bool(torch.equal(model.module.never.weight.detach(), never_before))
+    res["in_sync"] = model.check_replicas_in_sync()
+    _dump(out_dir, rank, res)
+    dist.cleanup()

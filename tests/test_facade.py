@@ -176,7 +176,7 @@ def test_launcher_refuses_more_ranks_than_gpus_unless_sharing_is_requested(monke
     with pytest.raises(ValueError, match="exceeds"):
         launcher.launch(lambda *a: None, nprocs=2)
 
-    def fake_spawn(fn, args, nprocs, env_per_rank, pin_cpus, join, monitor=None):
+    def fake_spawn(fn, args, nprocs, env_per_rank, pin_cpus, join, monitor=None, cpu_sets=None):
         calls["env"] = env_per_rank
 
     monkeypatch.setattr(launcher, "spawn", fake_spawn)
@@ -303,3 +303,40 @@ def test_cross_entropy_target_check_is_opt_in():
     ok = torch.tensor([0, 4, -100, 2])           # ignore_index is not an error
     ref = torch.nn.functional.cross_entropy(logits, ok)
     torch.testing.assert_close(softmax_cross_entropy(logits, ok, check_targets=True).loss, ref)
+
+
+def test_numa_local_cpu_slices_from_sysfs(tmp_path):
+    """CPU affinity follows the GPU's NUMA node: a fake sysfs with one CPU node, four GPUs on two NUMA
+    nodes; ranks on a node split that node's allowed CPUs, unknown topology falls back (None)."""
+    from distributed_pytorch_amd.parallel.launcher import gpu_numa_nodes, numa_cpu_slices, topology_cpu_slices, _parse_cpulist
+
+    root = tmp_path
+    nodes = root / "sys/class/kfd/kfd/topology/nodes"
+    layout = [(0, 0, None), (1, 64, (0, 0x05, 0)), (2, 64, (0, 0x15, 0)), (3, 64, (0, 0x85, 1)), (4, 64, (0, 0x95, 1))]
+    for nid, simd, pci in layout:
+        d = nodes / str(nid)
+        d.mkdir(parents=True)
+        loc = 0 if pci is None else (pci[1] << 8)
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\ndomain 0\nlocation_id {loc}\n")
+        if pci is not None:
+            p = root / f"sys/bus/pci/devices/0000:{pci[1]:02x}:00.0"
+            p.mkdir(parents=True)
+            (p / "numa_node").write_text(f"{pci[2]}\n")
+    for n, cpus in ((0, "0-3"), (1, "4-7")):
+        p = root / f"sys/devices/system/node/node{n}"
+        p.mkdir(parents=True)
+        (p / "cpulist").write_text(cpus + "\n")
+    assert gpu_numa_nodes(str(root)) == [0, 0, 1, 1]
+    assert _parse_cpulist("0-2,5,7-8") == [0, 1, 2, 5, 7, 8]
+    s = numa_cpu_slices([0, 1, 2, 3], [0, 0, 1, 1], {0: [0, 1, 2, 3], 1: [4, 5, 6, 7]}, range(8))
+    assert s == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    # rotated rank -> GPU assignment, restricted affinity mask
+    s = numa_cpu_slices([3, 0], [0, 0, 1, 1], {0: [0, 1, 2, 3], 1: [4, 5, 6, 7]}, [1, 2, 3, 6])
+    assert s == [[6], [1, 2, 3]]
+    assert numa_cpu_slices([0, 5], [0, 0, 1, 1], {0: [0], 1: [4]}, range(8)) is None      # GPU index without topology
+    assert numa_cpu_slices([0, 1], [0, 0], {0: [0]}, range(8)) is None                    # fewer CPUs than ranks
+    assert gpu_numa_nodes(str(tmp_path / "nowhere")) == []
+    import os
+    if set(range(8)) <= os.sched_getaffinity(0):
+        assert topology_cpu_slices(["2", "0"], str(root)) == [[4, 5, 6, 7], [0, 1, 2, 3]]
+    assert topology_cpu_slices(["GPU-abc"], str(root)) is None

@@ -291,3 +291,13 @@ def test_hang_monitor_decisions():
     now[0] += 21
     v = mon4.observe({0: (4, "run"), 1: (4, "run")})
     assert v is not None and v.kind == "stall" and v.ranks == [0, 1]
+
+
+def test_find_unused_parameters_keeps_globally_unused_grads_none(tmp_path):
+    dist.launch(mp_workers.ddp_unused_worker, str(tmp_path), nprocs=2)
+    r0, r1 = _read(tmp_path, 2)
+    for r in (r0, r1):
+        assert r["never_grad_is_none"] and r["never_untouched"] and r["in_sync"]
+        assert r["globally_unused"] == [4, 5]                      # never.weight, never.bias
+        # rank 0 contributes ones * 2 rows = 2 per output, rank 1 zeros: average 1
+        assert r["rank0_only_bias_grad"] == [1.0, 1.0, 1.0, 1.0]

@@ -277,6 +277,9 @@ __device__ __forceinline__ void softmax_strip(f32x4 (&s)[4], f32x4 (&o)[4], f32x
 }
 
 // One key tile for both 16-query strips of a wave.  MASK = the tile crosses the diagonal.
+// (Issuing both strips' score products before the first softmax, so that the second strip's matrix work
+// runs under the first strip's VALU work, was measured twice -- at three and at two waves per SIMD --
+// and is within run-to-run noise both times.)
 // The row sums of P come out of the matrix pipe: lsum[st] += 1^T P^T, one more 16x16x32 product per
 // strip and 32 keys with an all-ones A operand (every accumulator row then holds the sum for the
 // lane's query, of exactly the bf16 values that multiply V).  That replaces 32 VALU additions per

@@ -227,8 +227,18 @@ __global__ __launch_bounds__(THREADS) void xent_fwd_row_kernel(const typename TR
 __global__ __launch_bounds__(1024) void xent_scale_kernel(const long long* __restrict__ targets, long long N, long long ignore_index,
                                                           int mean, float* __restrict__ grad_scale) {
   __shared__ float scratch[16];
+  // One workgroup, fixed summation order; every thread takes four consecutive targets per step (two
+  // 16-byte loads) and the steps are independent, so the loop is bound by bandwidth, not by load latency.
   float valid = 0.f;
-  for (long long i = threadIdx.x; i < N; i += 1024) valid += (targets[i] != ignore_index) ? 1.f : 0.f;
+  const long long n4 = (reinterpret_cast<uintptr_t>(targets) & 15) == 0 ? N / 4 : 0;
+#pragma unroll 4
+  for (long long i = threadIdx.x; i < n4; i += 1024) {
+    const longlong2 a = *reinterpret_cast<const longlong2*>(targets + 4 * i);
+    const longlong2 b = *reinterpret_cast<const longlong2*>(targets + 4 * i + 2);
+    valid += (a.x != ignore_index ? 1.f : 0.f) + (a.y != ignore_index ? 1.f : 0.f) + (b.x != ignore_index ? 1.f : 0.f) +
+             (b.y != ignore_index ? 1.f : 0.f);
+  }
+  for (long long i = 4 * n4 + threadIdx.x; i < N; i += 1024) valid += (targets[i] != ignore_index) ? 1.f : 0.f;
   valid = block_sum<16>(valid, scratch);
   if (threadIdx.x == 0) grad_scale[0] = mean ? 1.f / fmaxf(valid, 1.f) : 1.f;
 }
@@ -271,10 +281,26 @@ __global__ __launch_bounds__(1024) void xent_reduce_kernel(const float* __restri
                                                            const long long* __restrict__ targets, long long N,
                                                            long long ignore_index, float* __restrict__ metrics) {
   __shared__ float scratch[16];
+  // One workgroup, fixed summation order (bit-reproducible metrics); four consecutive rows per thread and
+  // step with 16-byte / 4-byte vector loads, independent steps.
   float loss = 0.f, corr = 0.f, valid = 0.f;
-  for (long long i = threadIdx.x; i < N; i += 1024) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(row_loss) | reinterpret_cast<uintptr_t>(targets)) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(correct) & 3) == 0;
+  const long long n4 = aligned ? N / 4 : 0;
+#pragma unroll 4
+  for (long long i = threadIdx.x; i < n4; i += 1024) {
+    const f32x4 l = *reinterpret_cast<const f32x4*>(row_loss + 4 * i);
+    const unsigned c = *reinterpret_cast<const unsigned*>(correct + 4 * i);
+    const longlong2 a = *reinterpret_cast<const longlong2*>(targets + 4 * i);
+    const longlong2 b = *reinterpret_cast<const longlong2*>(targets + 4 * i + 2);
+    loss += (l[0] + l[1]) + (l[2] + l[3]);
+    corr += static_cast<float>(__builtin_popcount(c & 0x01010101u));
+    valid += (a.x != ignore_index ? 1.f : 0.f) + (a.y != ignore_index ? 1.f : 0.f) + (b.x != ignore_index ? 1.f : 0.f) +
+             (b.y != ignore_index ? 1.f : 0.f);
+  }
+  for (long long i = 4 * n4 + threadIdx.x; i < N; i += 1024) {
     loss += row_loss[i];
-    corr += correct[i];
+    corr += correct[i] ? 1.f : 0.f;
     valid += (targets[i] != ignore_index) ? 1.f : 0.f;
   }
   loss = block_sum<16>(loss, scratch);

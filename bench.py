@@ -58,7 +58,8 @@ def parse_args(argv=None):
                         "communication stream), to profile the overlap machinery on a single GPU")
     p.add_argument("--trace", action="store_true", help="emit roctx ranges (forward / backward / optimizer) for rocprofv3 --marker-trace")
     p.add_argument("--stock", action="store_true", help="comparison run: stock torch ops and torch.optim.AdamW(fused=True)")
-    p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph")
+    p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (default for --model dummy on one GPU, whose step is launch-bound)")
+    p.add_argument("--no-graph", action="store_true", help="launch every kernel of the step eagerly")
     p.add_argument("--json-out", default=None, help="also write the JSON line to this file")
     return p.parse_args(argv)
 
@@ -200,7 +201,8 @@ def run_rank(rank: int, world_size: int, argv):
 
     step = train_step
     graph = None
-    if args.graph and use_gpu and world_size == 1:
+    want_graph = (args.graph or args.model == "dummy") and not args.no_graph and not args.force_ddp
+    if want_graph and use_gpu and world_size == 1:
         from distributed_pytorch_amd.utils.graph import GraphedStep
 
         graph = GraphedStep(model, opt, loss_fn)

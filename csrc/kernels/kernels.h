@@ -156,7 +156,9 @@ void launch_colsum(const void* dy, void* db, float* workspace, long long M, long
 //   backward: grads (length rank1_mlp_bwd_len(H,N), NT = 4 | 8 | 16 >= N) holds
 //             dW2 rows at [n*H, (n+1)*H), dw1 at [NT*H, ...), db1 at [(NT+1)*H, ...), db2 at [(NT+2)*H, +N);
 //             partial: rank1_mlp_bwd_chunks(M,H) * rank1_mlp_bwd_len(H,N) floats of workspace.
-void launch_rank1_mlp_fwd(const void* x, const void* w1, const void* b1, const void* W2, const void* b2, void* y,
+//             pk: rank1_mlp_fwd_workspace(H, N) floats (the weights repacked for scalar streaming).
+long long rank1_mlp_fwd_workspace(long long H, long long N);
+void launch_rank1_mlp_fwd(const void* x, const void* w1, const void* b1, const void* W2, const void* b2, void* y, float* pk,
                           long long M, long long H, long long N, int dtype, int act, hipStream_t stream);
 int rank1_mlp_bwd_chunks(long long M, long long H);
 long long rank1_mlp_bwd_len(long long H, long long N);

@@ -404,8 +404,9 @@ Tensor rank1_mlp_forward(Tensor x, Tensor w1, c10::optional<Tensor> b1, Tensor W
   const void* b2p = opt_ptr(b2, w1, N, "b2");
   Tensor y = at::empty({M, N}, x.options());
   DevGuard g(x);
-  kernels::launch_rank1_mlp_fwd(x.data_ptr(), w1.data_ptr(), b1p, W2.data_ptr(), b2p, y.data_ptr(), M, H, N, kdtype(x),
-                                static_cast<int>(act), stream_of(x));
+  Tensor pk = at::empty({kernels::rank1_mlp_fwd_workspace(H, N)}, x.options().dtype(at::kFloat));
+  kernels::launch_rank1_mlp_fwd(x.data_ptr(), w1.data_ptr(), b1p, W2.data_ptr(), b2p, y.data_ptr(), pk.data_ptr<float>(), M, H, N,
+                                kdtype(x), static_cast<int>(act), stream_of(x));
   return y;
 }
 

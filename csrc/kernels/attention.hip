@@ -436,10 +436,8 @@ __device__ __forceinline__ void attn_fwd_block(const AttnParams& p, char* smem, 
                     o_stride, lane);
 }
 
-#ifndef ATTN_FWD_WGS
-#define ATTN_FWD_WGS 2
-#endif
-__global__ __launch_bounds__(kThreads, ATTN_FWD_WGS) void attn_fwd_kernel(AttnParams p) {
+// Two workgroups per CU: forcing three (168 registers) made the kernel 11 % slower.
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
   const int round = dispatch_round(p.per_cu);
   const int nqb = p.T / BQ, per_head = (nqb + 1) >> 1, n_items = per_head * p.B * p.H;
@@ -509,7 +507,7 @@ __device__ __forceinline__ bf16x8 row_frag(const char* tile, int t, int kk, int 
 template <bool MASK>
 __device__ __forceinline__ void dq_tile(const char* ks, const char* vs, const bf16x8 (&qf)[2][2], const bf16x8 (&dof)[2][2],
                                         f32x4 (&dq)[2][4], const float (&lse2)[2], const float (&dl)[2], int key0, int q0, int lane,
-                                        float c, float scale) {
+                                        float c) {
   const int g = lane >> 4, li = lane & 15;
   bf16x8 kf[4][2], vf[4][2];
 #pragma unroll
@@ -632,8 +630,8 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnBwdParams& p, char* 
     const char* vs = ks + kTileBytes;
     const int key0 = jt * BKV;
     if (key0 <= q0 + 31) {
-      if (key0 + BKV - 1 > q0) dq_tile<true>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2, p.scale);
-      else dq_tile<false>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2, p.scale);
+      if (key0 + BKV - 1 > q0) dq_tile<true>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2);
+      else dq_tile<false>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2);
     }
     stage = stage == 2 ? 0 : stage + 1;
   }
@@ -670,7 +668,7 @@ __device__ __forceinline__ void dma_4B(const float* src, unsigned lds_addr) {
 template <bool MASK>
 __device__ __forceinline__ void dkdv_tile(const char* qs_, const char* dos_, const bf16x8 (&kfB)[2][2], const bf16x8 (&vfB)[2][2],
                                           f32x4 (&dk)[2][4], f32x4 (&dv)[2][4], const char* stats, int hf, int qt0,
-                                          int k0w, int lane, float c, float scale) {
+                                          int k0w, int lane, float c) {
   // Works on the 32 queries qt0 .. qt0+31, which are rows 32*hf .. 32*hf+31 of the stage's tiles.
   const int g = lane >> 4, li = lane & 15;
   // per-register query statistics: query = qt0 + 16*qs + 4*g + e
@@ -816,8 +814,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_block(const AttnBwdParams& p, char
     for (int hf = 0; hf < 2; ++hf) {
       const int qt0 = (first_qt + it) * BQT + 32 * hf;
       if (qt0 + 31 >= k0w) {  // otherwise every query of the half precedes all of this wave's keys
-        if (qt0 < k0w + 31) dkdv_tile<true>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2, p.scale);
-        else dkdv_tile<false>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2, p.scale);
+        if (qt0 < k0w + 31) dkdv_tile<true>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2);
+        else dkdv_tile<false>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2);
       }
     }
     stage = stage == 2 ? 0 : stage + 1;

@@ -342,16 +342,6 @@ __device__ __forceinline__ void attn_fwd_block(const AttnParams& p, char* smem, 
   const u16* K = p.k + head_off;
   const u16* V = p.v + head_off;
 
-  // Q fragments (B operand): lane = query li of strip st, d = 32*kk + 8*g .. +7
-  bf16x8 qf[2][2];
-#pragma unroll
-  for (int st = 0; st < 2; ++st)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      qf[st][kk] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(q0 + 16 * st + li) * p.row_stride + 32 * kk + 8 * g);
-
-  wait_all_vmem();
-
   f32x4 o[2][4], lsum[2];
   float m[2];
 #pragma unroll
@@ -386,6 +376,15 @@ __device__ __forceinline__ void attn_fwd_block(const AttnParams& p, char* smem, 
   __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
   request(0);
   if (n_tiles > 1) request(1);
+  // Q fragments (B operand): lane = query li of strip st, d = 32*kk + 8*g .. +7.  Loaded AFTER the first
+  // tiles were requested, so that a block pays one trip to memory before its first product, not two.
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[st][kk] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(q0 + 16 * st + li) * p.row_stride + 32 * kk + 8 * g);
+  wait_all_vmem();
 #ifdef ATTN_STAMP
   const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -569,30 +568,6 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnBwdParams& p, char* 
   const u16* DO = p.d_o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
   const long long stat_off = (static_cast<long long>(b) * p.H + h) * p.T;
 
-  const u16* O = p.o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
-  bf16x8 qf[2][2], dof[2][2];
-  float lse2[2], dl[2];
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const int qi = q0 + 16 * st + li;
-    float part = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      qf[st][kk] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(qi) * p.row_stride + 32 * kk + 8 * g);
-      dof[st][kk] = *reinterpret_cast<const bf16x8*>(DO + static_cast<long long>(qi) * o_stride + 32 * kk + 8 * g);
-      const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + static_cast<long long>(qi) * o_stride + 32 * kk + 8 * g);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) part = fmaf(static_cast<float>(dof[st][kk][j]), static_cast<float>(of[j]), part);
-    }
-    lse2[st] = p.lse[stat_off + qi] * 1.4426950408889634f;
-    // delta = sum_d dO*O of this query: the four lane groups hold 16 d each
-    dl[st] = groups_sum(part);
-    if (g == 0) {
-      p.delta[stat_off + qi] = dl[st];
-      p.lse2[stat_off + qi] = lse2[st];
-    }
-  }
-  wait_all_vmem();
   f32x4 dq[2][4];
 #pragma unroll
   for (int st = 0; st < 2; ++st)
@@ -619,6 +594,32 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnBwdParams& p, char* 
   __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
   request(0);
   if (n_tiles > 1) request(1);
+  // The block's own rows are loaded after the first tiles were requested: one trip to memory before the
+  // first product, not two.
+  const u16* O = p.o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
+  bf16x8 qf[2][2], dof[2][2];
+  float lse2[2], dl[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int qi = q0 + 16 * st + li;
+    float part = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[st][kk] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(qi) * p.row_stride + 32 * kk + 8 * g);
+      dof[st][kk] = *reinterpret_cast<const bf16x8*>(DO + static_cast<long long>(qi) * o_stride + 32 * kk + 8 * g);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + static_cast<long long>(qi) * o_stride + 32 * kk + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part = fmaf(static_cast<float>(dof[st][kk][j]), static_cast<float>(of[j]), part);
+    }
+    lse2[st] = p.lse[stat_off + qi] * 1.4426950408889634f;
+    // delta = sum_d dO*O of this query: the four lane groups hold 16 d each
+    dl[st] = groups_sum(part);
+    if (g == 0) {
+      p.delta[stat_off + qi] = dl[st];
+      p.lse2[stat_off + qi] = lse2[st];
+    }
+  }
+  wait_all_vmem();
   int stage = 0;
   for (int jt = 0; jt < n_tiles; ++jt) {
     take_turns(jt + round);
@@ -745,17 +746,6 @@ __device__ __forceinline__ void attn_bwd_dkdv_block(const AttnBwdParams& p, char
   const float* lse2 = p.lse2 + stat_off;
   const float* delta = p.delta + stat_off;
 
-  // K / V fragments as B operands (col = key li of key tile kt2, k = d), resident for the whole kernel
-  bf16x8 kfB[2][2], vfB[2][2];
-#pragma unroll
-  for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const long long row = k0w + 16 * kt2 + li;
-      kfB[kt2][kk] = *reinterpret_cast<const bf16x8*>(K + row * p.row_stride + 32 * kk + 8 * g);
-      vfB[kt2][kk] = *reinterpret_cast<const bf16x8*>(V + row * p.row_stride + 32 * kk + 8 * g);
-    }
-  wait_all_vmem();
   f32x4 dk[2][4], dv[2][4];
 #pragma unroll
   for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -796,6 +786,18 @@ __device__ __forceinline__ void attn_bwd_dkdv_block(const AttnBwdParams& p, char
   __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
   request(0);
   if (n_iter > 1) request(1);
+  // (loaded after the first tiles were requested: one trip to memory before the first product, not two)
+  // K / V fragments as B operands (col = key li of key tile kt2, k = d), resident for the whole kernel
+  bf16x8 kfB[2][2], vfB[2][2];
+#pragma unroll
+  for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const long long row = k0w + 16 * kt2 + li;
+      kfB[kt2][kk] = *reinterpret_cast<const bf16x8*>(K + row * p.row_stride + 32 * kk + 8 * g);
+      vfB[kt2][kk] = *reinterpret_cast<const bf16x8*>(V + row * p.row_stride + 32 * kk + 8 * g);
+    }
+  wait_all_vmem();
   int stage = 0;
   for (int it = 0; it < n_iter; ++it) {
     take_turns(it + round);

@@ -35,17 +35,19 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(dpa::kernels::g_attn_stamps), sizeof(hs));
     int nwg = 0;
-    double loop = 0, tiles = 0, life = 0, sync = 0;
+    double loop = 0, tiles = 0, life = 0, sync = 0, life_rt = 0;
     unsigned long long t_min = ~0ull, t_max = 0;
     for (int i = 0; i < (1 << 12); ++i) {
       if (hs[i][1] == 0) continue;
       ++nwg;
       loop += hs[i][0]; tiles += hs[i][1]; life += hs[i][4]; sync += hs[i][5];
+      life_rt += double(hs[i][3] - hs[i][2]);
       if (hs[i][2] < t_min) t_min = hs[i][2];
       if (hs[i][3] > t_max) t_max = hs[i][3];
     }
     printf("  %d workgroups: loop %.0f cyc per tile (of which waiting at the barrier %.0f), %.0f tiles each; loop is %.1f %% of a workgroup's life; span %.1f us\n",
            nwg, loop / tiles, sync / tiles, tiles / nwg, 100.0 * loop / life, double(t_max - t_min) * 1e-2);
+    printf("  s_memtime ticks per microsecond of s_memrealtime (100 MHz): %.0f\n", life / (life_rt * 1e-2));
     int alive[16] = {0};
     for (int i = 0; i < (1 << 12); ++i) {
       if (hs[i][1] == 0) continue;

@@ -223,6 +223,143 @@ __global__ __launch_bounds__(THREADS) void xent_fwd_row_kernel(const typename TR
   }
 }
 
+// The fused kernel above for rows that fit in the workgroup's registers (16-bit logits, at most KEEP
+// 16-byte vectors per thread: a GPT-2 vocabulary row is 6288 vectors, 6.1 per thread of 1024): the row is
+// loaded ONCE, kept packed (4 registers per vector), reduced, turned into its gradient and stored, so the
+// tensor crosses the memory system exactly twice and nothing depends on the second read hitting a cache.
+// Requires 16-byte aligned rows of ld % 8 == 0 elements; columns C..ld-1 are padding (left out of the
+// softmax, zero-filled on output).
+template <typename TR, int THREADS, int KEEP>
+__global__ __launch_bounds__(THREADS, THREADS / 128) void xent_fused_resident_kernel(typename TR::T* logits, const long long* __restrict__ targets,
+                                                                      long long C, long long ld, long long ignore_index,
+                                                                      float* __restrict__ row_loss, unsigned char* __restrict__ correct,
+                                                                      const float* __restrict__ grad_scale) {
+  static_assert(TR::kVec == 8, "16-bit element types only");
+  constexpr int NW = THREADS / 64;
+  __shared__ float s_m[NW], s_s[NW], s_t[NW];
+  __shared__ int s_a[NW];
+  __shared__ float s_stats[2];
+  const long long r = blockIdx.x;
+  typename TR::T* row = logits + r * ld;
+  const long long tgt = targets[r];
+  const bool ignored = (tgt == ignore_index) || tgt < 0 || tgt >= C;
+  const int nvec = static_cast<int>((C + 7) / 8), nvec_ld = static_cast<int>(ld / 8);
+  const int cfull = static_cast<int>(C / 8), crem = static_cast<int>(C % 8);  // vector cfull holds crem real columns
+  const int tvec = ignored ? -1 : static_cast<int>(tgt >> 3), tsub = static_cast<int>(tgt & 7);
+
+  char* row_bytes = reinterpret_cast<char*>(row);
+  raw16 kept[KEEP];
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const int k = threadIdx.x + q * THREADS;
+    if (k < nvec) kept[q] = *reinterpret_cast<const raw16*>(row_bytes + 16u * static_cast<unsigned>(k));  // uniform base + 32-bit offset
+  }
+  auto element = [](const raw16& v, int j) { return TR::to_f32(static_cast<u16>(v[j >> 1] >> (16 * (j & 1)))); };
+
+  // this thread's maximum (lowest index among equals) and the target's logit if it holds it
+  float m = kNegInf, xt = 0.f;
+  int arg = 0x7fffffff;
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const int k = threadIdx.x + q * THREADS;
+    if (k < nvec) {
+      const int nval = k < cfull ? 8 : crem;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = j < nval ? element(kept[q], j) : kNegInf;
+        if (x > m) { m = x; arg = 8 * k + j; }
+        if (k == tvec && j == tsub) xt = x;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one vector at a time: interleaved, the expansions of all KEEP vectors would be live at once
+  }
+  // (the packed row is made opaque between the passes: otherwise the compiler keeps the fp32 expansions of
+  // the first pass for the later ones and spills them)
+  auto forget_expansions = [&]() {
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(kept[q][w]));
+  };
+  forget_expansions();
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const int k = threadIdx.x + q * THREADS;
+    if (k < nvec) {
+      const int nval = k < cfull ? 8 : crem;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += j < nval ? __expf(element(kept[q], j) - m) : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // Combine (m, s, arg, target logit) across the wave, then across waves.  Ties go to the lower index.
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float om = __shfl_xor(m, off, 64);
+    const float os = __shfl_xor(s, off, 64);
+    const int oa = __shfl_xor(arg, off, 64);
+    xt += __shfl_xor(xt, off, 64);
+    const float nm = fmaxf(m, om);
+    const float sa = (m == kNegInf) ? 0.f : s * __expf(m - nm);
+    const float sb = (om == kNegInf) ? 0.f : os * __expf(om - nm);
+    if (om > m || (om == m && oa < arg)) arg = oa;
+    m = nm;
+    s = sa + sb;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { s_m[wid] = m; s_s[wid] = s; s_a[wid] = arg; s_t[wid] = xt; }
+  __syncthreads();
+  if (wid == 0) {  // the first NW lanes combine the waves' results with the same exchange
+    static_assert(NW <= 64 && (NW & (NW - 1)) == 0, "one lane per wave, power of two");
+    const bool has = lane < NW;
+    m = has ? s_m[lane] : kNegInf;
+    s = has ? s_s[lane] : 0.f;
+    arg = has ? s_a[lane] : 0x7fffffff;
+    xt = has ? s_t[lane] : 0.f;
+#pragma unroll
+    for (int off = NW / 2; off > 0; off >>= 1) {
+      const float om = __shfl_xor(m, off, 64);
+      const float os = __shfl_xor(s, off, 64);
+      const int oa = __shfl_xor(arg, off, 64);
+      xt += __shfl_xor(xt, off, 64);
+      const float nm = fmaxf(m, om);
+      const float sa = (m == kNegInf) ? 0.f : s * __expf(m - nm);
+      const float sb = (om == kNegInf) ? 0.f : os * __expf(om - nm);
+      if (om > m || (om == m && oa < arg)) arg = oa;
+      m = nm;
+      s = sa + sb;
+    }
+    if (lane == 0) {
+      const float ls = __logf(s);
+      row_loss[r] = ignored ? 0.f : (m - xt) + ls;
+      correct[r] = (!ignored && arg == tgt) ? 1 : 0;
+      s_stats[0] = m;
+      s_stats[1] = ls;
+    }
+  }
+  __syncthreads();
+  forget_expansions();
+  const float shift = s_stats[0] + s_stats[1];  // x - max - log(sum)
+  const float g = ignored ? 0.f : grad_scale[0];
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const int k = threadIdx.x + q * THREADS;
+    if (k < nvec) {
+      const int nval = k < cfull ? 8 : crem;
+      float d[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        d[j] = j < nval ? (__expf(element(kept[q], j) - shift) - ((k == tvec && j == tsub) ? 1.f : 0.f)) * g : 0.f;
+      store_from_f32<TR, 8>(reinterpret_cast<typename TR::T*>(row_bytes + 16u * static_cast<unsigned>(k)), d);
+    } else if (k < nvec_ld) {
+      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      store_from_f32<TR, 8>(reinterpret_cast<typename TR::T*>(row_bytes + 16u * static_cast<unsigned>(k)), z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // grad_scale[0] = 1 / max(#targets != ignore_index, 1) for a mean, 1 for a sum.
 __global__ __launch_bounds__(1024) void xent_scale_kernel(const long long* __restrict__ targets, long long N, long long ignore_index,
                                                           int mean, float* __restrict__ grad_scale) {
@@ -377,6 +514,14 @@ void launch_xent_fused(void* logits, int dtype, const long long* targets, long l
     using TR = decltype(tr);
     using T = typename TR::T;
     T* lg = static_cast<T*>(logits);
+    constexpr int kKeep = 7;
+    if constexpr (TR::kVec == 8) {
+      if (C > 4096 && ld % 8 == 0 && ld / 8 <= kKeep * 1024 && (reinterpret_cast<uintptr_t>(lg) & 15) == 0) {
+        hipLaunchKernelGGL((xent_fused_resident_kernel<TR, 1024, kKeep>), dim3(static_cast<unsigned>(N)), dim3(1024), 0, stream, lg, targets,
+                           C, ld, ignore_index, row_loss, correct, grad_scale);
+        return;
+      }
+    }
     if (C <= 4096) {
       hipLaunchKernelGGL((xent_fwd_row_kernel<TR, 256, true>), dim3(static_cast<unsigned>(N)), dim3(256), 0, stream, lg, targets, C, ld,
                          ignore_index, row_loss, static_cast<float*>(nullptr), correct, grad_scale, lg);

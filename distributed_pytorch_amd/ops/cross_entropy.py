@@ -57,8 +57,9 @@ class _SoftmaxXent(torch.autograd.Function):
 
 class _ProjectionXent(torch.autograd.Function):
     """loss(x @ W^T): the vocabulary projection and its loss as ONE autograd node, so that the
-    gradient of the logits can be written by the same kernel launch that computes the loss (each
-    workgroup walks its row twice, the second time out of cache).  The node's backward is then only
+    gradient of the logits can be written by the same kernel launch that computes the loss (a 16-bit
+    row of up to 57344 columns stays in the workgroup's registers between the two passes; longer or
+    fp32 rows are read a second time, out of cache).  The node's backward is then only
     the two GEMMs; an upstream gradient other than 1 scales their (small) outputs instead of the
     [tokens, vocabulary] tensor."""
 

@@ -729,6 +729,38 @@ def test_projection_cross_entropy_fused_matches_reference(N, K, V, nc, dtype):
     assert torch.count_nonzero(ws.grad[nc:].float()) == 0  # padding classes get no gradient
 
 
+@pytest.mark.parametrize("ld,nc,dtype", [(8192, 8191, torch.bfloat16), (8192, 8192, torch.float16), (50304, 50257, torch.bfloat16),
+                                         (57344, 57344, torch.bfloat16), (57352, 57350, torch.bfloat16), (50304, 50257, torch.float32),
+                                         (4104, 4097, torch.bfloat16)])
+def test_fused_loss_kernel_row_in_registers_and_fallbacks(ld, nc, dtype):
+    """The in-place loss + gradient kernel on its own: 16-bit rows of up to 7 * 1024 vectors are kept in
+    registers (with the class count anywhere inside the last vector), longer and fp32 rows take the
+    two-read path; both against fp64, with ignored targets, ties and padding columns."""
+    from distributed_pytorch_amd import _ext
+
+    C = _ext.C()
+    torch.manual_seed(ld + nc)
+    N = 37
+    logits = (torch.randn(N, ld, device=DEV) * 4).to(dtype)
+    logits[3, 5] = logits[3, 9] = 30.0       # tie: the lower index is the prediction
+    logits[4, nc - 1] = 40.0                 # maximum in the last real column
+    logits[:, nc:] = 50.0                    # padding columns must not matter
+    t = torch.randint(0, nc, (N,), device=DEV)
+    t[3], t[4], t[5], t[6] = 5, nc - 1, -100, nc - 1
+    ref_in = logits[:, :nc].double().requires_grad_()
+    ref = F.cross_entropy(ref_in, t, ignore_index=-100)
+    ref.backward()
+    work = logits.clone()
+    correct, metrics = C.xent_fused(work, t, nc, -100, True)
+    valid = t != -100
+    torch.testing.assert_close(metrics[3].double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(correct, (ref_in.argmax(1) == t) & valid)
+    assert bool(correct[3]) and bool(correct[4]) and not bool(correct[5])
+    tol = dict(rtol=1e-4, atol=1e-7) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=2e-5)
+    torch.testing.assert_close(work[:, :nc].double(), ref_in.grad, **tol)
+    assert torch.count_nonzero(work[:, nc:]) == 0 and torch.count_nonzero(work[5]) == 0
+
+
 def test_add_layernorm_with_branch_bias_and_its_gradient():
     """s = x + r + r_bias in the forward kernel; the backward kernel also returns colsum(ds), the
     gradient of r_bias, next to dgamma / dbeta."""

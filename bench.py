@@ -262,7 +262,26 @@ def run_rank(rank: int, world_size: int, argv):
         "final_loss": round(final_loss, 5),
         "first_loss": round(float(first_loss.detach().float().item()), 5) if first_loss is not None else None,
     }
+    if use_gpu:
+        result["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
+        result["peak_reserved_gb"] = round(torch.cuda.max_memory_reserved(device) / 2**30, 2)
+    bail = None
     if use_gpu and on_rccl and not args.no_busbw:
+        # The extras below are collective: a rank that fails inside one of them leaves the others waiting.  Every
+        # rank therefore arms a deadline; when it passes, rank 0 prints the line it already has and all ranks
+        # leave without tearing the communicator down.
+        import threading
+
+        def _give_up():
+            if dist.is_primary():
+                result["extras"] = "abandoned after %d s" % int(extras_deadline)
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        extras_deadline = float(os.environ.get("BENCH_EXTRAS_DEADLINE_S", "120"))
+        bail = threading.Timer(extras_deadline, _give_up)
+        bail.daemon = True
+        bail.start()
         # After the timed region, never allowed to cost the result line:
         #  * overlap accounting over three extra steps: run time of the bucket all-reduces on the communication
         #    stream and how much of it the compute stream had to wait for (the part backward did not hide);
@@ -276,9 +295,8 @@ def run_rank(rank: int, world_size: int, argv):
             result["allreduce_busbw_gbps"] = _allreduce_busbw(pg, dist, device, max(world_size, 1))
         except Exception as exc:  # noqa: BLE001 - diagnostic extra only
             result["allreduce_busbw_gbps"] = f"failed: {type(exc).__name__}: {exc}"
-    if use_gpu:
-        result["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
-        result["peak_reserved_gb"] = round(torch.cuda.max_memory_reserved(device) / 2**30, 2)
+    if bail is not None:
+        bail.cancel()
     if dist.is_primary():
         line = json.dumps(result)
         print(line, flush=True)

@@ -69,19 +69,30 @@ class C10dTransport final : public Transport {
  public:
   explicit C10dTransport(c10::intrusive_ptr<c10d::ProcessGroup> pg) : pg_(std::move(pg)) {}
   bool native_average() const override { return false; }
+  // GPU tensors on a host-side group (gloo): the group stages them through pinned memory on streams of
+  // torch's pool, which first wait for an event of the compute stream.  With a long backlog on the compute
+  // stream (a real model's backward) that wait never returned on this runtime -- the stall described at
+  // RcclComm's own stream -- so the compute stream is drained first and the event is complete when waited on.
+  // This path is a plumbing configuration (several ranks sharing one GPU in tests), not a fast one.
+  static void drain_if_gpu(const at::Tensor& t) {
+    if (t.is_cuda()) c10::hip::getCurrentHIPStream(t.get_device()).synchronize();
+  }
   void all_reduce_async(at::Tensor flat, int /*slot*/, bool /*average: pre-divided by the reducer*/) override {
+    drain_if_gpu(flat);
     std::vector<at::Tensor> ts{flat};
     c10d::AllreduceOptions o;
     o.reduceOp = c10d::ReduceOp::SUM;
     works_.push_back(pg_->allreduce(ts, o));
   }
   void broadcast(at::Tensor flat, int root) override {
+    drain_if_gpu(flat);
     std::vector<at::Tensor> ts{flat};
     c10d::BroadcastOptions o;
     o.rootRank = root;
     pg_->broadcast(ts, o)->wait();
   }
   void all_reduce_sum_blocking(at::Tensor t) override {
+    drain_if_gpu(t);
     std::vector<at::Tensor> ts{t};
     c10d::AllreduceOptions o;
     o.reduceOp = c10d::ReduceOp::SUM;

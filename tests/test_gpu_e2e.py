@@ -417,6 +417,28 @@ def test_bench_two_ranks_on_one_gpu_gloo_ddp_contract():
     assert r["steps"] == 2 and r["warmup"] == 1 and r["value"] > 0
 
 
+def test_full_size_gpt2_two_ranks_on_one_gpu_over_gloo():
+    """Two ranks sharing the GPU, GPT-2 small at full width under the reducer with the host-side (gloo)
+    data plane: the backward leaves a long backlog on the compute stream when the first bucket is reduced,
+    which used to stall the group's staging streams for good (the transport now drains the stream first)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ)
+    env["PYTHONPATH"] = str(root) + os.pathsep + env.get("PYTHONPATH", "")
+    env["HIP_VISIBLE_DEVICES"] = "0"
+    env["DIST_ALLOW_GPU_SHARING"] = "1"
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch-size", "4", "--steps", "2",
+                        "--warmup", "1"], cwd=str(root), env=env, timeout=110, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["config"]["model"] == "gpt2-small" and r["config"]["comm"] == "gloo"
+    assert r["final_loss"] < r["first_loss"]
+
+
 def test_rccl_group_through_torch_distributed_run_store():
     """The rendezvous path of the multi-GPU benchmark (torch.distributed.run hosts the store on
     MASTER_PORT, the ncclUniqueId travels through it), at the world size one GPU allows."""

@@ -185,6 +185,24 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const
                           void* dsum, float* workspace, long long rows, long long cols, int dtype,
                           hipStream_t stream);
 
+// ------------------------------------------------------------------ batch normalisation (training mode, channels last)
+// x, y, residual, dy, dx: row-major [R, C] (R = batch * height * width positions) in `dtype`; gamma, beta and their
+// gradients: [C] in `param_dtype`; running statistics: [C] in `stat_dtype`; mean, rstd: fp32 [C].  relu != 0 folds
+// y = max(., 0) into the forward and its mask (y > 0) into the backward; a residual is added before the ReLU.
+bool batchnorm_supported(long long R, long long C, int dtype);
+long long batchnorm_workspace(long long R, long long C, int dtype);  // floats, for either direction
+// Statistics of x, y = relu(x * a + b (+ res)); a | b are left in scale_shift [2*C]; gamma / beta / running_* may be null.
+void launch_batchnorm_fwd(const void* x, const void* res, void* y, const void* gamma, const void* beta, int param_dtype, void* running_mean,
+                          void* running_var, int stat_dtype, float momentum, float eps, float* mean, float* rstd, float* scale_shift,
+                          float* workspace, long long R, long long C, int relu, int dtype, hipStream_t stream);
+// y = relu(x * scale + shift (+ res)) with given per-channel fp32 coefficients (evaluation mode).
+void launch_batchnorm_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, long long R, long long C, int relu,
+                            int dtype, hipStream_t stream);
+// dx, dgamma, dbeta (either may be null) and dres = masked dy when dres != nullptr; y is read only when relu != 0.
+void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const void* gamma, int param_dtype, const float* mean,
+                          const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* workspace, long long R, long long C,
+                          int relu, int dtype, hipStream_t stream);
+
 // ------------------------------------------------------------------ causal attention (head dim 64, bf16)
 // q/k/v element (b, t, h, d) lives at ptr[(b*T + t) * row_stride + h*64 + d] (a packed
 // [B, T, 3, H, 64] projection has row_stride = 3*H*64 and k = q + H*64, v = q + 2*H*64).

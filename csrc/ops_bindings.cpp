@@ -291,6 +291,127 @@ std::tuple<Tensor, Tensor> xent_fused(Tensor logits, Tensor targets, int64_t n_c
   return {correct, metrics};
 }
 
+// ------------------------------------------------------------------ batch normalisation (training mode, channels last)
+// x: [R, C] (the channels-last activation flattened over batch and space).  Returns (y, mean, rstd).
+// running_mean / running_var are updated in place when given.
+std::tuple<Tensor, Tensor, Tensor> batchnorm_forward(Tensor x, c10::optional<Tensor> gamma, c10::optional<Tensor> beta,
+                                                     c10::optional<Tensor> running_mean, c10::optional<Tensor> running_var, double momentum,
+                                                     double eps, c10::optional<Tensor> residual, bool relu) {
+  check_gpu(x, "x");
+  TORCH_CHECK(x.dim() == 2 && x.is_contiguous(), "batchnorm_forward: x must be a contiguous [R, C] tensor");
+  const int64_t R = x.size(0), C = x.size(1);
+  const int dt = kdtype(x);
+  TORCH_CHECK(kernels::batchnorm_supported(R, C, dt), "batchnorm_forward: unsupported shape [", R, ", ", C, "]");
+  int pdt = kernels::kF32, sdt = kernels::kF32;
+  const void *gp = nullptr, *bp = nullptr;
+  if (gamma.has_value() && gamma->defined()) {
+    check_gpu(*gamma, "weight");
+    TORCH_CHECK(gamma->numel() == C && gamma->is_contiguous(), "batchnorm_forward: weight must be [C]");
+    pdt = kdtype(*gamma);
+    gp = gamma->data_ptr();
+  }
+  if (beta.has_value() && beta->defined()) {
+    check_gpu(*beta, "bias");
+    TORCH_CHECK(beta->numel() == C && beta->is_contiguous(), "batchnorm_forward: bias must be [C]");
+    TORCH_CHECK(gp == nullptr || kdtype(*beta) == pdt, "batchnorm_forward: weight and bias dtypes differ");
+    pdt = kdtype(*beta);
+    bp = beta->data_ptr();
+  }
+  void *rm = nullptr, *rv = nullptr;
+  if (running_mean.has_value() && running_mean->defined()) {
+    check_gpu(*running_mean, "running_mean");
+    TORCH_CHECK(running_var.has_value() && running_var->defined(), "batchnorm_forward: running_mean without running_var");
+    check_gpu(*running_var, "running_var");
+    TORCH_CHECK(running_mean->numel() == C && running_var->numel() == C && running_mean->is_contiguous() && running_var->is_contiguous() &&
+                    running_mean->scalar_type() == running_var->scalar_type(),
+                "batchnorm_forward: running statistics must be contiguous [C] tensors of one dtype");
+    sdt = kdtype(*running_mean);
+    rm = running_mean->data_ptr();
+    rv = running_var->data_ptr();
+  }
+  const void* rp = nullptr;
+  if (residual.has_value() && residual->defined()) {
+    check_gpu(*residual, "residual");
+    TORCH_CHECK(residual->sizes() == x.sizes() && residual->scalar_type() == x.scalar_type() && residual->is_contiguous() &&
+                    residual->get_device() == x.get_device(),
+                "batchnorm_forward: residual must match x");
+    rp = residual->data_ptr();
+  }
+  auto fopt = x.options().dtype(at::kFloat);
+  Tensor y = at::empty_like(x), mean = at::empty({C}, fopt), rstd = at::empty({C}, fopt), ss = at::empty({2 * C}, fopt);
+  Tensor ws = at::empty({kernels::batchnorm_workspace(R, C, dt)}, fopt);
+  DevGuard g(x);
+  kernels::launch_batchnorm_fwd(x.data_ptr(), rp, y.data_ptr(), gp, bp, pdt, rm, rv, sdt, static_cast<float>(momentum), static_cast<float>(eps),
+                                mean.data_ptr<float>(), rstd.data_ptr<float>(), ss.data_ptr<float>(), ws.data_ptr<float>(), R, C, relu ? 1 : 0, dt,
+                                stream_of(x));
+  return {y, mean, rstd};
+}
+
+// y = relu(x * scale + shift (+ residual)) with fp32 per-channel coefficients (evaluation mode).
+Tensor batchnorm_apply(Tensor x, Tensor scale, Tensor shift, c10::optional<Tensor> residual, bool relu) {
+  check_gpu(x, "x");
+  check_gpu(scale, "scale");
+  check_gpu(shift, "shift");
+  TORCH_CHECK(x.dim() == 2 && x.is_contiguous(), "batchnorm_apply: x must be a contiguous [R, C] tensor");
+  const int64_t R = x.size(0), C = x.size(1);
+  const int dt = kdtype(x);
+  TORCH_CHECK(kernels::batchnorm_supported(R, C, dt), "batchnorm_apply: unsupported shape");
+  TORCH_CHECK(scale.scalar_type() == at::kFloat && shift.scalar_type() == at::kFloat && scale.numel() == C && shift.numel() == C &&
+                  scale.is_contiguous() && shift.is_contiguous(),
+              "batchnorm_apply: scale and shift must be contiguous fp32 [C]");
+  const void* rp = nullptr;
+  if (residual.has_value() && residual->defined()) {
+    check_gpu(*residual, "residual");
+    TORCH_CHECK(residual->sizes() == x.sizes() && residual->scalar_type() == x.scalar_type() && residual->is_contiguous(),
+                "batchnorm_apply: residual must match x");
+    rp = residual->data_ptr();
+  }
+  Tensor y = at::empty_like(x);
+  DevGuard g(x);
+  kernels::launch_batchnorm_apply(x.data_ptr(), rp, y.data_ptr(), scale.data_ptr<float>(), shift.data_ptr<float>(), R, C, relu ? 1 : 0, dt,
+                                  stream_of(x));
+  return y;
+}
+
+// Returns (dx, dgamma, dbeta, dres); dgamma / dbeta in the dtype of gamma (fp32 without one), dres undefined unless wanted.
+std::tuple<Tensor, Tensor, Tensor, Tensor> batchnorm_backward(Tensor dy, Tensor x, c10::optional<Tensor> y, c10::optional<Tensor> gamma,
+                                                              Tensor mean, Tensor rstd, bool relu, bool want_dres) {
+  check_gpu(dy, "dy");
+  check_gpu(x, "x");
+  TORCH_CHECK(x.dim() == 2 && x.is_contiguous() && dy.is_contiguous() && dy.sizes() == x.sizes() && dy.scalar_type() == x.scalar_type() &&
+                  dy.get_device() == x.get_device(),
+              "batchnorm_backward: dy and x must be matching contiguous [R, C] tensors");
+  const int64_t R = x.size(0), C = x.size(1);
+  const int dt = kdtype(x);
+  TORCH_CHECK(kernels::batchnorm_supported(R, C, dt), "batchnorm_backward: unsupported shape");
+  TORCH_CHECK(mean.scalar_type() == at::kFloat && rstd.scalar_type() == at::kFloat && mean.numel() == C && rstd.numel() == C,
+              "batchnorm_backward: mean and rstd must be fp32 [C]");
+  const void* yp = nullptr;
+  if (relu) {
+    TORCH_CHECK(y.has_value() && y->defined() && y->sizes() == x.sizes() && y->scalar_type() == x.scalar_type() && y->is_contiguous(),
+                "batchnorm_backward: the fused ReLU needs the forward output");
+    yp = y->data_ptr();
+  }
+  int pdt = kernels::kF32;
+  const void* gp = nullptr;
+  auto popt = x.options().dtype(at::kFloat);
+  if (gamma.has_value() && gamma->defined()) {
+    check_gpu(*gamma, "weight");
+    TORCH_CHECK(gamma->numel() == C && gamma->is_contiguous(), "batchnorm_backward: weight must be [C]");
+    pdt = kdtype(*gamma);
+    gp = gamma->data_ptr();
+    popt = gamma->options();
+  }
+  Tensor dx = at::empty_like(x), dgamma = at::empty({C}, popt), dbeta = at::empty({C}, popt), dres;
+  if (want_dres) dres = at::empty_like(x);
+  Tensor ws = at::empty({kernels::batchnorm_workspace(R, C, dt)}, x.options().dtype(at::kFloat));
+  DevGuard g(x);
+  kernels::launch_batchnorm_bwd(dy.data_ptr(), x.data_ptr(), yp, gp, pdt, mean.data_ptr<float>(), rstd.data_ptr<float>(), dx.data_ptr(),
+                                want_dres ? dres.data_ptr() : nullptr, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr<float>(), R, C,
+                                relu ? 1 : 0, dt, stream_of(x));
+  return {dx, dgamma, dbeta, dres};
+}
+
 // ------------------------------------------------------------------ linear layers
 bool gemm_path_ok(const kernels::GemmArgs& a, int dt) {
   return dt == kernels::kF32 ? kernels::gemm_f32_supported(a) : (dt == kernels::kBF16 ? kernels::gemm_bf16_supported(a) : false);
@@ -750,6 +871,15 @@ void init_ops(py::module_& m) {
   m.def("colsum", &colsum);
   m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),
         py::arg("act") = 0);
+  m.def("batchnorm_supported", [](int64_t R, int64_t C, const std::string& dtype) {
+    return kernels::batchnorm_supported(R, C, dtype == "float32" ? kernels::kF32 : (dtype == "bfloat16" ? kernels::kBF16 : kernels::kF16));
+  });
+  m.def("batchnorm_forward", &batchnorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("running_mean"), py::arg("running_var"),
+        py::arg("momentum"), py::arg("eps"), py::arg("residual") = py::none(), py::arg("relu") = false);
+  m.def("batchnorm_apply", &batchnorm_apply, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("residual") = py::none(),
+        py::arg("relu") = false);
+  m.def("batchnorm_backward", &batchnorm_backward, py::arg("dy"), py::arg("x"), py::arg("y"), py::arg("weight"), py::arg("mean"), py::arg("rstd"),
+        py::arg("relu") = false, py::arg("want_dres") = false);
   m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5,
         py::arg("res") = py::none(), py::arg("res_bias") = py::none());
   m.def("layernorm_backward", &layernorm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"), py::arg("rstd"),

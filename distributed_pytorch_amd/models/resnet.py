@@ -1,15 +1,17 @@
 """ResNet-50 (bottleneck v1.5: stride on the 3x3 convolution), defined from scratch for the
-"ResNet-50, synthetic 224 x 224, bf16" data-parallel configuration.  Convolutions and batch
-norm run on the vendor library through torch (MIOpen) in channels-last layout; the classifier
-head, the loss (fused softmax cross-entropy + accuracy), the optimizer and the gradient
-reducer are this framework's kernels.  BatchNorm running statistics are module buffers,
-which the DDP wrapper keeps in one flat tensor and re-broadcasts from rank 0 each step.
+"ResNet-50, synthetic 224 x 224, bf16" data-parallel configuration.  Convolutions run on the
+vendor library through torch (MIOpen) in channels-last layout; batch norm (with the ReLU and
+the residual add of a block folded into it), the classifier head, the loss (fused softmax
+cross-entropy + accuracy), the optimizer and the gradient reducer are this framework's
+kernels.  BatchNorm running statistics are module buffers, which the DDP wrapper keeps in one
+flat tensor and re-broadcasts from rank 0 each step.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+from ..ops.batchnorm import BatchNorm2d
 from ..ops.linear import Linear
 
 
@@ -19,20 +21,18 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: nn.Module | None = None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn3 = BatchNorm2d(planes * self.expansion)
         self.downsample = downsample
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=identity, relu=True)  # relu(bn3(.) + identity) in one pass
 
 
 class ResNet(nn.Module):
@@ -40,8 +40,7 @@ class ResNet(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = BatchNorm2d(64)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
         self.layer1 = self._make_layer(64, layers[0])
         self.layer2 = self._make_layer(128, layers[1], stride=2)
@@ -64,7 +63,7 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != planes * Bottleneck.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(self.inplanes, planes * Bottleneck.expansion, 1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes * Bottleneck.expansion),
+                BatchNorm2d(planes * Bottleneck.expansion),
             )
         seq = [Bottleneck(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * Bottleneck.expansion
@@ -72,7 +71,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)

@@ -851,3 +851,103 @@ def test_dgrad_act_backward_gelu_table_over_all_magnitudes():
     err = (g.double() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 2e-3).all(), err.max().item()
     torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-2, atol=0.15)
+
+
+# ----------------------------------------------------------------------------- batch normalisation (channels last)
+@pytest.mark.parametrize("shape", [(8, 64, 28, 28), (3, 64, 7, 5), (4, 256, 14, 14), (2, 2048, 7, 7), (5, 512, 3, 3), (16, 128, 1, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu,residual", [(False, False), (True, False), (True, True), (False, True)])
+def test_batchnorm_training_forward_backward(shape, dtype, relu, residual):
+    """relu(bn(x) + residual) with batch statistics against fp64 autograd on the same (rounded) inputs: output,
+    running statistics, and the gradients of x, weight, bias and the residual."""
+    from distributed_pytorch_amd.ops import BatchNorm2d
+
+    torch.manual_seed(sum(shape) + relu + 2 * residual)
+    n, c, h, w = shape
+    x = (torch.randn(shape, device=DEV) * 1.5 + 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(shape, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last) if residual else None
+    bn = BatchNorm2d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, device=DEV) + 0.5)
+        bn.bias.copy_(torch.randn(c, device=DEV) * 0.2)
+    ref = torch.nn.BatchNorm2d(c).to(DEV).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    xs = x.clone().requires_grad_()
+    rs = r.clone().requires_grad_() if residual else None
+    y = bn(xs, residual=rs, relu=relu)
+    assert y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last)
+    go = torch.randn(shape, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+
+    xd = x.double().requires_grad_()
+    rd = r.double().requires_grad_() if residual else None
+    yd = ref(xd)
+    if residual:
+        yd = yd + rd
+    if relu:
+        yd = torch.relu(yd)
+    yd.backward(go.double())
+    lo = dtype == torch.bfloat16
+    torch.testing.assert_close(y.double(), yd.detach(), rtol=2e-2 if lo else 1e-4, atol=3e-2 if lo else 1e-4)
+    torch.testing.assert_close(bn.running_mean.double(), ref.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn.running_var.double(), ref.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+    # where the bf16 output rounds to a different side of zero than the fp64 one, the ReLU masks differ: compare the
+    # gradients only where both agree (everywhere for fp32 up to measure zero)
+    agree = ((y.double() > 0) == (yd > 0)) if relu else torch.ones_like(yd, dtype=torch.bool)
+    frac = agree.double().mean().item()
+    assert frac > (0.99 if lo else 0.9999)
+    scale = go.double().abs().mean() * (bn.weight.double().abs().mean())
+    gx_err = ((xs.grad.double() - xd.grad) * agree).abs().mean() / scale
+    assert gx_err < (2e-2 if lo else 1e-4), gx_err
+    if residual:
+        torch.testing.assert_close((rs.grad.double() * agree), (rd.grad * agree), rtol=1e-2 if lo else 1e-5, atol=1e-2 if lo else 1e-6)
+    if frac == 1.0:
+        rows = n * h * w
+        tol = dict(rtol=3e-2, atol=3e-2 * rows ** 0.5) if lo else dict(rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(bn.weight.grad.double(), ref.weight.grad, **tol)
+        torch.testing.assert_close(bn.bias.grad.double(), ref.bias.grad, **tol)
+
+
+def test_batchnorm_offset_channels_determinism_eval_and_bf16_module():
+    """Statistics of channels with a large common offset (variance must not cancel), bitwise repeatability of the
+    two-stage reductions, the evaluation-mode path, and a module converted with .to(bfloat16) (bf16 affine
+    parameters and running statistics, as the ResNet benchmark uses it)."""
+    from distributed_pytorch_amd.ops import BatchNorm2d
+
+    torch.manual_seed(11)
+    c = 128
+    x = (torch.randn(6, c, 9, 9, device=DEV) * 0.01 + 1000.0).contiguous(memory_format=torch.channels_last)
+    bn = BatchNorm2d(c).to(DEV)
+    y = bn(x)
+    ref = torch.nn.functional.batch_norm(x.double(), None, None, bn.weight.double(), bn.bias.double(), True, 0.1, bn.eps)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-2, atol=2e-2)   # fp32 input near 1000 carries ~6e-5 of rounding on a 1e-2 spread
+    assert abs(float(y.detach().double().var()) - 1e-4 / (1e-4 + bn.eps)) < 0.02   # the spread survived the offset (eps = 1e-5 on a variance of 1e-4)
+
+    xb = torch.randn(32, c, 14, 14, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for _ in range(2):
+        m = BatchNorm2d(c).to(DEV)
+        xs = xb.clone().requires_grad_()
+        out = m(xs, relu=True)
+        out.backward(torch.ones_like(out))
+        outs.append((out.detach().clone(), xs.grad.clone(), m.weight.grad.clone(), m.running_var.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+    m = BatchNorm2d(c).to(DEV).to(torch.bfloat16)
+    assert m.weight.dtype == torch.bfloat16 and m.running_mean.dtype == torch.bfloat16
+    r = torch.randn_like(xb)
+    out = m(xb.clone().requires_grad_(), residual=r, relu=True)
+    out.float().sum().backward()
+    assert m.weight.grad.dtype == torch.bfloat16 and torch.isfinite(m.weight.grad.float()).all()
+    refm = torch.nn.BatchNorm2d(c).to(DEV).to(torch.bfloat16)
+    torch.testing.assert_close(out.float(), torch.relu(refm(xb) + r).float(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(m.running_var.float(), refm.running_var.float(), rtol=2e-2, atol=2e-2)
+    m.eval()
+    with torch.no_grad():
+        e = m(xb, residual=r, relu=True)
+        refm.eval()
+        torch.testing.assert_close(e.float(), torch.relu(refm(xb) + r).float(), rtol=3e-2, atol=3e-2)
+    # same keys as the stock module
+    assert list(m.state_dict().keys()) == list(refm.state_dict().keys())

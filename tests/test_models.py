@@ -132,3 +132,23 @@ def test_gpt2_gpu_training_steps_track_stock_torch():
     assert lo[-1] < lo[0] and lr_[-1] < lr_[0]
     for a, b in zip(lo, lr_):
         assert abs(a - b) < 5e-2 * abs(b), (lo, lr_)
+
+
+def test_batchnorm_module_cpu_fallback_matches_stock_module():
+    """Off the GPU the module is torch's batch norm followed by the add and the ReLU, with identical state."""
+    import torch.nn.functional as F
+
+    from distributed_pytorch_amd.ops import BatchNorm2d
+
+    torch.manual_seed(0)
+    x = torch.randn(4, 16, 5, 5)
+    r = torch.randn(4, 16, 5, 5)
+    a, b = BatchNorm2d(16), torch.nn.BatchNorm2d(16)
+    b.load_state_dict(a.state_dict())
+    ya = a(x, residual=r, relu=True)
+    yb = F.relu(b(x) + r)
+    torch.testing.assert_close(ya, yb)
+    torch.testing.assert_close(a.running_var, b.running_var)
+    assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+    a.eval(); b.eval()
+    torch.testing.assert_close(a(x), b(x))

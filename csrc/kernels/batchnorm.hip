@@ -13,8 +13,8 @@
 //                                                   bn_bwd_partial_kernel -> bn_bwd_finalize_kernel
 //            dx = (g - dbeta / R - xhat * dgamma / R) * a  (and d residual = g)   bn_bwd_apply_kernel
 //
-// Reductions over rows are two-stage and fixed-order (a partial per row chunk, then one thread per channel
-// adds the chunks in index order), so results are bitwise reproducible.  The variance is accumulated as
+// Reductions over rows are two-stage and fixed-order (a partial per row chunk, then a fixed tree over the chunks
+// per channel), so results are bitwise reproducible.  The variance is accumulated as
 // (count, mean, M2) triples merged with Chan's formula; inside a thread the sums are taken relative to the
 // thread's first element, so a large common offset of a channel does not cancel away the variance.
 // Lanes read 16 bytes of consecutive channels; a workgroup covers up to 256 such vectors of a row and
@@ -145,25 +145,49 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_partial_kernel(const type
   }
 }
 
-// One thread per channel: merges the chunks in index order; writes the saved statistics, the affine form of the
-// normalisation and, when given, the running statistics (unbiased variance, as torch.nn.BatchNorm2d keeps them).
+// The second stage of both reductions: a workgroup takes 16 channels, its 16 x 16 threads split the chunks into 16
+// contiguous segments (thread = segment * 16 + channel), every thread folds its segment in index order and the
+// segment results are folded in segment order -- a fixed tree, so the result does not depend on timing.
+constexpr int kFinChannels = 16, kFinSegments = kBnThreads / kFinChannels;
+
+// Merges the chunks' (count, mean, M2); writes the saved statistics, the affine form of the normalisation and, when
+// given, the running statistics (unbiased variance, as torch.nn.BatchNorm2d keeps them).
 __global__ __launch_bounds__(kBnThreads) void bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, long long rows_per_chunk,
                                                                        long long R, long long C, const void* __restrict__ gamma,
                                                                        const void* __restrict__ beta, int param_dtype, float eps, float momentum,
                                                                        void* __restrict__ running_mean, void* __restrict__ running_var,
                                                                        int stat_dtype, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                                        float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  const long long c = static_cast<long long>(blockIdx.x) * kBnThreads + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float s_mean[kBnThreads], s_m2[kBnThreads], s_cnt[kBnThreads];
+  const int ch = threadIdx.x % kFinChannels, seg = threadIdx.x / kFinChannels;
+  const long long c = static_cast<long long>(blockIdx.x) * kFinChannels + ch;
+  const int per_seg = (chunks + kFinSegments - 1) / kFinSegments;
+  const int k0 = seg * per_seg, k1 = k0 + per_seg < chunks ? k0 + per_seg : chunks;
   float mean = 0.f, m2 = 0.f, cnt = 0.f;
+  if (c < C) {
 #pragma unroll 4
-  for (int k = 0; k < chunks; ++k) {
-    const long long r0 = k * rows_per_chunk;
-    const float nb = static_cast<float>((r0 + rows_per_chunk < R ? r0 + rows_per_chunk : R) - r0);
-    const float mb = partial[static_cast<long long>(k) * 2 * C + c], qb = partial[static_cast<long long>(k) * 2 * C + C + c];
-    const float tot = cnt + nb, w = nb / tot, d = mb - mean;
+    for (int k = k0; k < k1; ++k) {
+      const long long r0 = k * rows_per_chunk;
+      const float nb = static_cast<float>((r0 + rows_per_chunk < R ? r0 + rows_per_chunk : R) - r0);
+      const float mb = partial[static_cast<long long>(k) * 2 * C + c], qb = partial[static_cast<long long>(k) * 2 * C + C + c];
+      const float tot = cnt + nb, w = nb * __builtin_amdgcn_rcpf(tot), d = mb - mean;
+      mean = fmaf(d, w, mean);
+      m2 += qb + d * d * cnt * w;
+      cnt = tot;
+    }
+  }
+  s_mean[threadIdx.x] = mean;
+  s_m2[threadIdx.x] = m2;
+  s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  if (seg != 0 || c >= C) return;
+  for (int sg = 1; sg < kFinSegments; ++sg) {
+    const int o = sg * kFinChannels + ch;
+    const float nb = s_cnt[o];
+    if (nb == 0.f) continue;
+    const float tot = cnt + nb, w = nb / tot, d = s_mean[o] - mean;
     mean = fmaf(d, w, mean);
-    m2 += qb + d * d * cnt * w;
+    m2 += s_m2[o] + d * d * cnt * w;
     cnt = tot;
   }
   const float var = fmaxf(m2 / static_cast<float>(R), 0.f);
@@ -288,13 +312,26 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_finalize_kernel(const float
                                                                      const void* __restrict__ gamma, int param_dtype,
                                                                      const float* __restrict__ rstd, void* __restrict__ dgamma,
                                                                      void* __restrict__ dbeta, float* __restrict__ coef) {
-  const long long c = static_cast<long long>(blockIdx.x) * kBnThreads + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float s_1[kBnThreads], s_2[kBnThreads];
+  const int ch = threadIdx.x % kFinChannels, seg = threadIdx.x / kFinChannels;
+  const long long c = static_cast<long long>(blockIdx.x) * kFinChannels + ch;
+  const int per_seg = (chunks + kFinSegments - 1) / kFinSegments;
+  const int k0 = seg * per_seg, k1 = k0 + per_seg < chunks ? k0 + per_seg : chunks;
   float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
 #pragma unroll 8
-  for (int k = 0; k < chunks; ++k) {
-    s1 += partial[static_cast<long long>(k) * 2 * C + c];
-    s2 += partial[static_cast<long long>(k) * 2 * C + C + c];
+    for (int k = k0; k < k1; ++k) {
+      s1 += partial[static_cast<long long>(k) * 2 * C + c];
+      s2 += partial[static_cast<long long>(k) * 2 * C + C + c];
+    }
+  }
+  s_1[threadIdx.x] = s1;
+  s_2[threadIdx.x] = s2;
+  __syncthreads();
+  if (seg != 0 || c >= C) return;
+  for (int sg = 1; sg < kFinSegments; ++sg) {
+    s1 += s_1[sg * kFinChannels + ch];
+    s2 += s_2[sg * kFinChannels + ch];
   }
   if (dbeta) chan_store(dbeta, c, param_dtype, s1);
   if (dgamma) chan_store(dgamma, c, param_dtype, s2);
@@ -343,7 +380,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const typename
   }
 }
 
-// Row chunks: enough workgroups to fill the chip a few times over, at least 8 passes of rows each.
+// Row chunks: enough workgroups to fill the chip a few times over, at least 32 passes of rows each.
 void bn_chunks(long long R, long long C, int vec, long long& rows_per_chunk, int& chunks, int& col_blocks) {
   const long long cv = C / vec;
   col_blocks = static_cast<int>((cv + kBnThreads - 1) / kBnThreads);
@@ -352,7 +389,7 @@ void bn_chunks(long long R, long long C, int vec, long long& rows_per_chunk, int
   long long want = 1024 / col_blocks;
   if (want < 1) want = 1;
   rows_per_chunk = (R + want - 1) / want;
-  const long long min_rows = 8 * rpp;
+  const long long min_rows = 32 * rpp;
   if (rows_per_chunk < min_rows) rows_per_chunk = min_rows;
   rows_per_chunk = (rows_per_chunk + rpp - 1) / rpp * rpp;
   chunks = static_cast<int>((R + rows_per_chunk - 1) / rows_per_chunk);
@@ -400,7 +437,7 @@ void launch_batchnorm_fwd(const void* x, const void* res, void* y, const void* g
     bn_chunks(R, C, V, rows_per_chunk, chunks, col_blocks);
     hipLaunchKernelGGL((bn_stats_partial_kernel<TR>), dim3(chunks, col_blocks), dim3(kBnThreads), 0, stream, static_cast<const T*>(x), R, C,
                        rows_per_chunk, workspace);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(static_cast<unsigned>((C + kBnThreads - 1) / kBnThreads)), dim3(kBnThreads), 0, stream,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(static_cast<unsigned>((C + kFinChannels - 1) / kFinChannels)), dim3(kBnThreads), 0, stream,
                        workspace, chunks, rows_per_chunk, R, C, gamma, beta, param_dtype, eps, momentum, running_mean, running_var, stat_dtype,
                        mean, rstd, scale_shift, scale_shift + C);
     const long long cv = C / V, n_vec = R * cv;
@@ -465,7 +502,7 @@ void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const vo
     else
       hipLaunchKernelGGL((bn_bwd_partial_kernel<TR, false>), dim3(chunks, col_blocks), dim3(kBnThreads), 0, stream, dyp, xp, yp, mean, rstd, R, C,
                          rows_per_chunk, workspace);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(static_cast<unsigned>((C + kBnThreads - 1) / kBnThreads)), dim3(kBnThreads), 0, stream,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(static_cast<unsigned>((C + kFinChannels - 1) / kFinChannels)), dim3(kBnThreads), 0, stream,
                        workspace, chunks, R, C, gamma, param_dtype, rstd, dgamma, dbeta, coef);
     const long long cv = C / V, n_vec = R * cv;
     const dim3 grid(bn_stream_grid(n_vec, cv));

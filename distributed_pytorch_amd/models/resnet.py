@@ -1,6 +1,7 @@
 """ResNet-50 (bottleneck v1.5: stride on the 3x3 convolution), defined from scratch for the
-"ResNet-50, synthetic 224 x 224, bf16" data-parallel configuration.  Convolutions run on the
-vendor library through torch (MIOpen) in channels-last layout; batch norm (with the ReLU and
+"ResNet-50, synthetic 224 x 224, bf16" data-parallel configuration.  The 3x3 / 7x7 / strided
+convolutions run on the vendor library through torch (MIOpen) in channels-last layout; the 1x1
+stride-1 convolutions (a GEMM over channels-last rows), batch norm (with the ReLU and
 the residual add of a block folded into it), the classifier head, the loss (fused softmax
 cross-entropy + accuracy), the optimizer and the gradient reducer are this framework's
 kernels.  BatchNorm running statistics are module buffers, which the DDP wrapper keeps in one
@@ -12,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from ..ops.batchnorm import BatchNorm2d
+from ..ops.conv import PointwiseConv2d
 from ..ops.linear import Linear
 
 
@@ -20,11 +22,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: nn.Module | None = None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = PointwiseConv2d(inplanes, planes)
         self.bn1 = BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
         self.bn2 = BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.conv3 = PointwiseConv2d(planes, planes * self.expansion)
         self.bn3 = BatchNorm2d(planes * self.expansion)
         self.downsample = downsample
 
@@ -62,7 +64,7 @@ class ResNet(nn.Module):
         downsample = None
         if stride != 1 or self.inplanes != planes * Bottleneck.expansion:
             downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * Bottleneck.expansion, 1, stride=stride, bias=False),
+                PointwiseConv2d(self.inplanes, planes * Bottleneck.expansion, stride=stride),
                 BatchNorm2d(planes * Bottleneck.expansion),
             )
         seq = [Bottleneck(self.inplanes, planes, stride, downsample)]

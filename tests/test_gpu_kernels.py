@@ -951,3 +951,27 @@ def test_batchnorm_offset_channels_determinism_eval_and_bf16_module():
         torch.testing.assert_close(e.float(), torch.relu(refm(xb) + r).float(), rtol=3e-2, atol=3e-2)
     # same keys as the stock module
     assert list(m.state_dict().keys()) == list(refm.state_dict().keys())
+
+
+@pytest.mark.parametrize("n,cin,cout,hw", [(8, 256, 1024, 14), (4, 512, 128, 9), (2, 2048, 512, 7), (3, 64, 256, 10)])
+def test_pointwise_conv_as_gemm_matches_stock_convolution(n, cin, cout, hw):
+    """1x1 stride-1 convolution over channels-last bf16 activations on the GEMM kernels (layers narrower than 128
+    channels stay on the stock path): output and all gradients against the fp32 convolution of the same values."""
+    from distributed_pytorch_amd.ops import PointwiseConv2d
+
+    torch.manual_seed(cin + cout)
+    conv = PointwiseConv2d(cin, cout).to(DEV).bfloat16().to(memory_format=torch.channels_last)
+    x = torch.randn(n, cin, hw, hw, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    go = torch.randn(n, cout, hw, hw, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    y = conv(x)
+    assert y.shape == (n, cout, hw, hw) and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    xr = x.detach().float().requires_grad_()
+    wr = conv.weight.detach().float().requires_grad_()
+    yr = F.conv2d(xr, wr)
+    yr.backward(go.float())
+    torch.testing.assert_close(y.float(), yr.detach(), rtol=2e-2, atol=2e-2 * cin ** 0.5 * 0.1)
+    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=2e-2, atol=2e-2 * cout ** 0.5 * 0.1)
+    assert conv.weight.grad.shape == conv.weight.shape
+    werr = (conv.weight.grad.float() - wr.grad).norm() / wr.grad.norm()
+    assert werr < 1e-2, werr

@@ -152,3 +152,14 @@ def test_batchnorm_module_cpu_fallback_matches_stock_module():
     assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
     a.eval(); b.eval()
     torch.testing.assert_close(a(x), b(x))
+
+
+def test_pointwise_conv_cpu_fallback_and_state_dict():
+    from distributed_pytorch_amd.ops import PointwiseConv2d
+
+    torch.manual_seed(1)
+    a, b = PointwiseConv2d(8, 12, stride=2), torch.nn.Conv2d(8, 12, 1, stride=2, bias=False)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, 8, 6, 6)
+    torch.testing.assert_close(a(x), b(x))
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())

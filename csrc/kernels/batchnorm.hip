@@ -245,12 +245,19 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const typename TR:
   }
 }
 
-// partial[chunk][0][c] = sum g, partial[chunk][1][c] = sum g * xhat over the chunk's rows; g = dy where y > 0 (RELU) or dy.
-template <typename TR, bool RELU>
+// How the backward finds the ReLU mask: not at all, from the saved output (y > 0), or -- when nothing was added
+// before the ReLU -- from x itself: y = relu(x * a + b) is positive exactly where x * a + b is (rounding the fp32
+// value to the activation dtype cannot change its sign), with a | b the forward's own coefficients, so the output
+// need not be read.
+constexpr int kMaskNone = 0, kMaskFromY = 1, kMaskFromX = 2;
+
+// partial[chunk][0][c] = sum g, partial[chunk][1][c] = sum g * xhat over the chunk's rows; g = dy under the ReLU mask.
+template <typename TR, int MASK>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_partial_kernel(const typename TR::T* __restrict__ dy, const typename TR::T* __restrict__ x,
                                                                     const typename TR::T* __restrict__ y, const float* __restrict__ mean,
-                                                                    const float* __restrict__ rstd, long long R, long long C,
-                                                                    long long rows_per_chunk, float* __restrict__ partial) {
+                                                                    const float* __restrict__ rstd, const float* __restrict__ scale_shift,
+                                                                    long long R, long long C, long long rows_per_chunk,
+                                                                    float* __restrict__ partial) {
   constexpr int V = TR::kVec;
   __shared__ float s_a[kBnThreads * V], s_b[kBnThreads * V];
   const BnTile t = bn_tile<V>(C);
@@ -260,21 +267,26 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_partial_kernel(const typena
 #pragma unroll
   for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.f;
   if (t.active) {
-    float mu[V], rs[V];
+    float mu[V], rs[V], a[V], b[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       mu[j] = mean[t.col0 + j];
       rs[j] = rstd[t.col0 + j];
+      a[j] = MASK == kMaskFromX ? scale_shift[t.col0 + j] : 0.f;
+      b[j] = MASK == kMaskFromX ? scale_shift[C + t.col0 + j] : 0.f;
     }
     for (long long r = r0 + t.rl; r < r1; r += t.rpp) {
       float g[V], xv[V];
       load_as_f32<TR, V>(dy + r * C + t.col0, g);
       load_as_f32<TR, V>(x + r * C + t.col0, xv);
-      if (RELU) {
+      if (MASK == kMaskFromY) {
         float yv[V];
         load_as_f32<TR, V>(y + r * C + t.col0, yv);
 #pragma unroll
         for (int j = 0; j < V; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+      } else if (MASK == kMaskFromX) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = fmaf(xv[j], a[j], b[j]) > 0.f ? g[j] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -342,18 +354,18 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_finalize_kernel(const float
 }
 
 // dx = (g - c1 - xhat * c2) * a; dres = g (when the block's residual branch needs its gradient).
-template <typename TR, bool RELU, bool DRES>
+template <typename TR, int MASK, bool DRES>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const typename TR::T* __restrict__ dy, const typename TR::T* __restrict__ x,
                                                                   const typename TR::T* __restrict__ y, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ coef,
-                                                                  typename TR::T* __restrict__ dx, typename TR::T* __restrict__ dres,
-                                                                  long long n_vec, long long cv, long long C) {
+                                                                  const float* __restrict__ scale_shift, typename TR::T* __restrict__ dx,
+                                                                  typename TR::T* __restrict__ dres, long long n_vec, long long cv, long long C) {
   constexpr int V = TR::kVec;
   const long long stride = static_cast<long long>(gridDim.x) * kBnThreads;
   long long i = static_cast<long long>(blockIdx.x) * kBnThreads + threadIdx.x;
   if (i >= n_vec) return;
   const long long c0 = (i % cv) * V;
-  float mu[V], rs[V], a[V], c1[V], c2[V];
+  float mu[V], rs[V], a[V], c1[V], c2[V], fa[V], fb[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     mu[j] = mean[c0 + j];
@@ -361,16 +373,21 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const typename
     a[j] = coef[c0 + j];
     c1[j] = coef[C + c0 + j];
     c2[j] = coef[2 * C + c0 + j];
+    fa[j] = MASK == kMaskFromX ? scale_shift[c0 + j] : 0.f;
+    fb[j] = MASK == kMaskFromX ? scale_shift[C + c0 + j] : 0.f;
   }
   for (; i < n_vec; i += stride) {
     float g[V], xv[V];
     load_as_f32<TR, V>(dy + i * V, g);
     load_as_f32<TR, V>(x + i * V, xv);
-    if (RELU) {
+    if (MASK == kMaskFromY) {
       float yv[V];
       load_as_f32<TR, V>(y + i * V, yv);
 #pragma unroll
       for (int j = 0; j < V; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+    } else if (MASK == kMaskFromX) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) g[j] = fmaf(xv[j], fa[j], fb[j]) > 0.f ? g[j] : 0.f;
     }
     if (DRES) store_from_f32<TR, V>(dres + i * V, g);
     float d[V];
@@ -482,9 +499,11 @@ void launch_batchnorm_apply(const void* x, const void* res, void* y, const float
   });
 }
 
-void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const void* gamma, int param_dtype, const float* mean,
-                          const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* workspace, long long R, long long C,
-                          int relu, int dtype, hipStream_t stream) {
+void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const float* scale_shift, const void* gamma, int param_dtype,
+                          const float* mean, const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* workspace, long long R,
+                          long long C, int relu, int dtype, hipStream_t stream) {
+  // the mask comes from x when the forward's coefficients are given (no residual was added), else from y
+  const int mask = !relu ? kMaskNone : (scale_shift != nullptr ? kMaskFromX : kMaskFromY);
   dispatch_dtype(dtype, [&](auto tr) {
     using TR = decltype(tr);
     using T = typename TR::T;
@@ -496,28 +515,26 @@ void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const vo
     const T* dyp = static_cast<const T*>(dy);
     const T* xp = static_cast<const T*>(x);
     const T* yp = static_cast<const T*>(y);
-    if (relu)
-      hipLaunchKernelGGL((bn_bwd_partial_kernel<TR, true>), dim3(chunks, col_blocks), dim3(kBnThreads), 0, stream, dyp, xp, yp, mean, rstd, R, C,
-                         rows_per_chunk, workspace);
-    else
-      hipLaunchKernelGGL((bn_bwd_partial_kernel<TR, false>), dim3(chunks, col_blocks), dim3(kBnThreads), 0, stream, dyp, xp, yp, mean, rstd, R, C,
-                         rows_per_chunk, workspace);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(static_cast<unsigned>((C + kFinChannels - 1) / kFinChannels)), dim3(kBnThreads), 0, stream,
-                       workspace, chunks, R, C, gamma, param_dtype, rstd, dgamma, dbeta, coef);
-    const long long cv = C / V, n_vec = R * cv;
-    const dim3 grid(bn_stream_grid(n_vec, cv));
     T* dxp = static_cast<T*>(dx);
     T* drp = static_cast<T*>(dres);
-    auto go = [&](auto relu_c, auto dres_c) {
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<TR, decltype(relu_c)::value, decltype(dres_c)::value>), grid, dim3(kBnThreads), 0, stream, dyp, xp,
-                         yp, mean, rstd, coef, dxp, drp, n_vec, cv, C);
+    const long long cv = C / V, n_vec = R * cv;
+    const dim3 grid(bn_stream_grid(n_vec, cv));
+    auto go = [&](auto mask_c) {
+      constexpr int M = decltype(mask_c)::value;
+      hipLaunchKernelGGL((bn_bwd_partial_kernel<TR, M>), dim3(chunks, col_blocks), dim3(kBnThreads), 0, stream, dyp, xp, yp, mean, rstd,
+                         scale_shift, R, C, rows_per_chunk, workspace);
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(static_cast<unsigned>((C + kFinChannels - 1) / kFinChannels)), dim3(kBnThreads), 0, stream,
+                         workspace, chunks, R, C, gamma, param_dtype, rstd, dgamma, dbeta, coef);
+      if (dres)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<TR, M, true>), grid, dim3(kBnThreads), 0, stream, dyp, xp, yp, mean, rstd, coef, scale_shift, dxp,
+                           drp, n_vec, cv, C);
+      else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<TR, M, false>), grid, dim3(kBnThreads), 0, stream, dyp, xp, yp, mean, rstd, coef, scale_shift, dxp,
+                           drp, n_vec, cv, C);
     };
-    constexpr std::true_type yes{};
-    constexpr std::false_type no{};
-    if (relu && dres) go(yes, yes);
-    else if (relu) go(yes, no);
-    else if (dres) go(no, yes);
-    else go(no, no);
+    if (mask == kMaskFromX) go(std::integral_constant<int, kMaskFromX>{});
+    else if (mask == kMaskFromY) go(std::integral_constant<int, kMaskFromY>{});
+    else go(std::integral_constant<int, kMaskNone>{});
   });
 }
 

@@ -198,10 +198,12 @@ void launch_batchnorm_fwd(const void* x, const void* res, void* y, const void* g
 // y = relu(x * scale + shift (+ res)) with given per-channel fp32 coefficients (evaluation mode).
 void launch_batchnorm_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, long long R, long long C, int relu,
                             int dtype, hipStream_t stream);
-// dx, dgamma, dbeta (either may be null) and dres = masked dy when dres != nullptr; y is read only when relu != 0.
-void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const void* gamma, int param_dtype, const float* mean,
-                          const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* workspace, long long R, long long C,
-                          int relu, int dtype, hipStream_t stream);
+// dx, dgamma, dbeta (either may be null) and dres = masked dy when dres != nullptr.  With relu != 0 the mask is
+// y > 0, read from y -- or, when scale_shift (the forward's a | b, [2*C]) is given, recomputed from x: valid when
+// no residual was added before the ReLU, and then y is not touched.
+void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const float* scale_shift, const void* gamma, int param_dtype,
+                          const float* mean, const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* workspace, long long R,
+                          long long C, int relu, int dtype, hipStream_t stream);
 
 // ------------------------------------------------------------------ causal attention (head dim 64, bf16)
 // q/k/v element (b, t, h, d) lives at ptr[(b*T + t) * row_stride + h*64 + d] (a packed

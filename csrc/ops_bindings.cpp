@@ -292,9 +292,9 @@ std::tuple<Tensor, Tensor> xent_fused(Tensor logits, Tensor targets, int64_t n_c
 }
 
 // ------------------------------------------------------------------ batch normalisation (training mode, channels last)
-// x: [R, C] (the channels-last activation flattened over batch and space).  Returns (y, mean, rstd).
+// x: [R, C] (the channels-last activation flattened over batch and space).  Returns (y, mean, rstd, scale | shift).
 // running_mean / running_var are updated in place when given.
-std::tuple<Tensor, Tensor, Tensor> batchnorm_forward(Tensor x, c10::optional<Tensor> gamma, c10::optional<Tensor> beta,
+std::tuple<Tensor, Tensor, Tensor, Tensor> batchnorm_forward(Tensor x, c10::optional<Tensor> gamma, c10::optional<Tensor> beta,
                                                      c10::optional<Tensor> running_mean, c10::optional<Tensor> running_var, double momentum,
                                                      double eps, c10::optional<Tensor> residual, bool relu) {
   check_gpu(x, "x");
@@ -344,7 +344,7 @@ std::tuple<Tensor, Tensor, Tensor> batchnorm_forward(Tensor x, c10::optional<Ten
   kernels::launch_batchnorm_fwd(x.data_ptr(), rp, y.data_ptr(), gp, bp, pdt, rm, rv, sdt, static_cast<float>(momentum), static_cast<float>(eps),
                                 mean.data_ptr<float>(), rstd.data_ptr<float>(), ss.data_ptr<float>(), ws.data_ptr<float>(), R, C, relu ? 1 : 0, dt,
                                 stream_of(x));
-  return {y, mean, rstd};
+  return {y, mean, rstd, ss};
 }
 
 // y = relu(x * scale + shift (+ residual)) with fp32 per-channel coefficients (evaluation mode).
@@ -374,8 +374,9 @@ Tensor batchnorm_apply(Tensor x, Tensor scale, Tensor shift, c10::optional<Tenso
 }
 
 // Returns (dx, dgamma, dbeta, dres); dgamma / dbeta in the dtype of gamma (fp32 without one), dres undefined unless wanted.
-std::tuple<Tensor, Tensor, Tensor, Tensor> batchnorm_backward(Tensor dy, Tensor x, c10::optional<Tensor> y, c10::optional<Tensor> gamma,
-                                                              Tensor mean, Tensor rstd, bool relu, bool want_dres) {
+// The ReLU mask comes from y, or from x and the forward's coefficients `scale_shift` when those are given instead.
+std::tuple<Tensor, Tensor, Tensor, Tensor> batchnorm_backward(Tensor dy, Tensor x, c10::optional<Tensor> y, c10::optional<Tensor> scale_shift,
+                                                              c10::optional<Tensor> gamma, Tensor mean, Tensor rstd, bool relu, bool want_dres) {
   check_gpu(dy, "dy");
   check_gpu(x, "x");
   TORCH_CHECK(x.dim() == 2 && x.is_contiguous() && dy.is_contiguous() && dy.sizes() == x.sizes() && dy.scalar_type() == x.scalar_type() &&
@@ -387,9 +388,15 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> batchnorm_backward(Tensor dy, Tensor 
   TORCH_CHECK(mean.scalar_type() == at::kFloat && rstd.scalar_type() == at::kFloat && mean.numel() == C && rstd.numel() == C,
               "batchnorm_backward: mean and rstd must be fp32 [C]");
   const void* yp = nullptr;
-  if (relu) {
+  const float* ssp = nullptr;
+  if (relu && scale_shift.has_value() && scale_shift->defined()) {
+    check_gpu(*scale_shift, "scale_shift");
+    TORCH_CHECK(scale_shift->scalar_type() == at::kFloat && scale_shift->numel() == 2 * C && scale_shift->is_contiguous(),
+                "batchnorm_backward: scale_shift must be contiguous fp32 [2*C]");
+    ssp = scale_shift->data_ptr<float>();
+  } else if (relu) {
     TORCH_CHECK(y.has_value() && y->defined() && y->sizes() == x.sizes() && y->scalar_type() == x.scalar_type() && y->is_contiguous(),
-                "batchnorm_backward: the fused ReLU needs the forward output");
+                "batchnorm_backward: the fused ReLU needs the forward output or the forward's coefficients");
     yp = y->data_ptr();
   }
   int pdt = kernels::kF32;
@@ -406,7 +413,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> batchnorm_backward(Tensor dy, Tensor 
   if (want_dres) dres = at::empty_like(x);
   Tensor ws = at::empty({kernels::batchnorm_workspace(R, C, dt)}, x.options().dtype(at::kFloat));
   DevGuard g(x);
-  kernels::launch_batchnorm_bwd(dy.data_ptr(), x.data_ptr(), yp, gp, pdt, mean.data_ptr<float>(), rstd.data_ptr<float>(), dx.data_ptr(),
+  kernels::launch_batchnorm_bwd(dy.data_ptr(), x.data_ptr(), yp, ssp, gp, pdt, mean.data_ptr<float>(), rstd.data_ptr<float>(), dx.data_ptr(),
                                 want_dres ? dres.data_ptr() : nullptr, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr<float>(), R, C,
                                 relu ? 1 : 0, dt, stream_of(x));
   return {dx, dgamma, dbeta, dres};
@@ -878,8 +885,8 @@ void init_ops(py::module_& m) {
         py::arg("momentum"), py::arg("eps"), py::arg("residual") = py::none(), py::arg("relu") = false);
   m.def("batchnorm_apply", &batchnorm_apply, py::arg("x"), py::arg("scale"), py::arg("shift"), py::arg("residual") = py::none(),
         py::arg("relu") = false);
-  m.def("batchnorm_backward", &batchnorm_backward, py::arg("dy"), py::arg("x"), py::arg("y"), py::arg("weight"), py::arg("mean"), py::arg("rstd"),
-        py::arg("relu") = false, py::arg("want_dres") = false);
+  m.def("batchnorm_backward", &batchnorm_backward, py::arg("dy"), py::arg("x"), py::arg("y"), py::arg("scale_shift"), py::arg("weight"),
+        py::arg("mean"), py::arg("rstd"), py::arg("relu") = false, py::arg("want_dres") = false);
   m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5,
         py::arg("res") = py::none(), py::arg("res_bias") = py::none());
   m.def("layernorm_backward", &layernorm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"), py::arg("rstd"),

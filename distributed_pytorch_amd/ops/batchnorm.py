@@ -54,15 +54,17 @@ def _native_ok(x: torch.Tensor, residual: Optional[torch.Tensor]) -> bool:
 
 
 class _BatchNormAct(torch.autograd.Function):
-    """y = relu(batch_norm(x) + residual) with batch statistics (training mode).  Saves x, the statistics and --
-    for the ReLU mask -- y, which the next layer keeps alive anyway."""
+    """y = relu(batch_norm(x) + residual) with batch statistics (training mode).  Saves x and the statistics; for
+    the ReLU mask the forward's per-channel coefficients (the mask is recomputed from x) or, when a residual was
+    added before the ReLU, the output y, which the next layer keeps alive anyway."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum: float, eps: float, residual, relu: bool):
         x2 = _rows(x)
         r2 = _rows(residual) if residual is not None else None
-        y2, mean, rstd = _ext.C().batchnorm_forward(x2, weight, bias, running_mean, running_var, momentum, eps, r2, relu)
-        ctx.save_for_backward(x2, y2 if relu else None, weight, mean, rstd)
+        y2, mean, rstd, coef = _ext.C().batchnorm_forward(x2, weight, bias, running_mean, running_var, momentum, eps, r2, relu)
+        mask_from_x = relu and residual is None
+        ctx.save_for_backward(x2, y2 if relu and not mask_from_x else None, coef if mask_from_x else None, weight, mean, rstd)
         ctx.relu = relu
         ctx.has_residual = residual is not None
         ctx.shape = tuple(x.shape)
@@ -70,13 +72,13 @@ class _BatchNormAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x2, y2, weight, mean, rstd = ctx.saved_tensors
+        x2, y2, coef, weight, mean, rstd = ctx.saved_tensors
         shape = ctx.shape
         if len(shape) == 4 and not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dy2 = _rows(dy) if len(shape) == 4 else dy.contiguous()
         want_dres = ctx.has_residual and ctx.needs_input_grad[7] and ctx.relu
-        dx2, dgamma, dbeta, dres2 = _ext.C().batchnorm_backward(dy2, x2, y2, weight, mean, rstd, ctx.relu, want_dres)
+        dx2, dgamma, dbeta, dres2 = _ext.C().batchnorm_backward(dy2, x2, y2, coef, weight, mean, rstd, ctx.relu, want_dres)
         dres = None
         if ctx.has_residual and ctx.needs_input_grad[7]:
             dres = _like(dres2, shape) if ctx.relu else dy  # without the ReLU the residual's gradient is dy itself

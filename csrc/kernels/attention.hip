@@ -193,7 +193,8 @@ constexpr int kOutStripBytes = 32 * kOutPitch;
 // colsum[c]): the piece of a bias gradient that belongs to these rows.
 // STREAM: the rows leave through non-temporal stores.  The gradient tensors are read by nobody before the kernel
 // ends, while the K / V (Q / dO) rows are re-read from L2 by the head's other blocks; written the normal way the
-// gradients evict them (backward 290 -> 277 us at B32; the forward's single output tensor makes no difference).
+// gradients evict them (backward 290 -> 277 us at B32; the forward's single output tensor makes no difference
+// there, and a small one in the training step: 351.6 -> 350.5 ms).
 template <bool STREAM = false>
 __device__ __forceinline__ void store_rows_staged(char* strip, const f32x4 (&acc)[2][4], const float (&row_scale)[2], u16* out,
                                                   long long row_stride, int lane, float* colsum = nullptr) {
@@ -436,7 +437,7 @@ __device__ __forceinline__ void attn_fwd_block(const AttnParams& p, char* smem, 
   }
   __syncthreads();  // all waves are done with the tile stages: their memory becomes the output strips
   const long long o_stride = static_cast<long long>(p.H) * HD;
-  store_rows_staged(smem + wid * kOutStripBytes, o, inv, p.o + (static_cast<long long>(b) * p.T + q0) * o_stride + static_cast<long long>(h) * HD,
+  store_rows_staged<true>(smem + wid * kOutStripBytes, o, inv, p.o + (static_cast<long long>(b) * p.T + q0) * o_stride + static_cast<long long>(h) * HD,
                     o_stride, lane);
 }
 

@@ -407,8 +407,9 @@ constexpr int kNoTile = 0x7fffffff;
 using lds_u32_ptr = volatile __attribute__((address_space(3))) unsigned*;
 constexpr int kStreamingMaxKSteps = 64;  // beyond K = 4096 a tile is long enough to hide its own start
 
-// SPLIT: blockIdx.y selects a contraction range of `k_iters` steps; raw fp32 partial tiles go to
-// p.workspace[blockIdx.y][M][N] (16-byte stores) and splitk_reduce_kernel finishes the product.
+// SPLIT: the grid is (tiles, ranges); every workgroup multiplies one contraction range of `k_iters` steps of one
+// tile; raw fp32 partial tiles go to p.workspace[range][M][N] (16-byte stores) and splitk_reduce_kernel finishes
+// the product.
 //
 // tile_counter == nullptr: one tile per workgroup (grid = number of tiles, XCD-aware order).
 // tile_counter != nullptr: the grid is at most one workgroup per CU and every workgroup walks a
@@ -438,12 +439,24 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
 
   const bool dynamic = !SPLIT && tile_counter != nullptr;
   const int ntiles = tiles_m * tiles_n;
+  // SPLIT: the (range, tile) pairs are dealt to the XCDs as one list, range-major: workgroup L of the launch
+  // (XCD L % 8) takes a contiguous eighth of it, so an XCD's ~32 workgroups multiply the SAME contraction range of
+  // neighbouring tiles and share every operand panel through their L2.  Taken per range instead (tile from
+  // blockIdx.x, range from blockIdx.y) an XCD holds 4-5 tiles of each of the ~7 ranges and fetches ~2.3x the panels.
+  int split_idx = 0, first_id = blockIdx.x;
+  if (SPLIT) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, W = gridDim.x * gridDim.y;
+    const int q = W >> 3, r = W & 7, x = L & 7;
+    const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (L >> 3);
+    split_idx = w / ntiles;
+    first_id = w - split_idx * ntiles;
+  }
   // Tile id -> origin.  Ids are laid out in groups of 8 row-tiles x all column-tiles, row-tile fastest: the
   // tiles being worked on at any time then form blocks that share operand panels in L2 (an 8 x 4 block
   // touches 12 panels per k-step instead of the 33 of a single column of tiles, +9 % on 8192^3).  With one
   // tile per workgroup each XCD (workgroups b, b+8, ...) additionally gets a contiguous run of ids.
   auto tile_origin = [&](int id, long long& m0, long long& n0) __attribute__((always_inline)) {
-    if (!dynamic) {
+    if (!dynamic && !SPLIT) {
       const int q = ntiles >> 3, r = ntiles & 7, xcd = id & 7;
       id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)smem2));
 
   const long long nk_all = p.K / BK2;
-  const long long kt0 = SPLIT ? static_cast<long long>(blockIdx.y) * k_iters : 0;
+  const long long kt0 = SPLIT ? static_cast<long long>(split_idx) * k_iters : 0;
   const long long nk_end = SPLIT ? (kt0 + k_iters < nk_all ? kt0 + k_iters : nk_all) : nk_all;
   const int n = static_cast<int>(nk_end - kt0);  // k-steps per tile
 
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   const char *r_aptr = nullptr, *r_bptr = nullptr;
   unsigned r_dst = lds_base + wid * 2048;  // this wave's first piece of half-tile 0 in the buffer being filled
   bool r_valid = true;
-  int cur = blockIdx.x;                                                     // tile being multiplied
+  int cur = first_id;                                                       // tile being multiplied
   int nxt = dynamic ? static_cast<int>(blockIdx.x + gridDim.x) : kNoTile;   // tile after it
   // per-lane source offsets of the cursor's tile (recomputed after every epilogue rather than kept across it)
   auto set_offsets = [&](int id) __attribute__((always_inline)) {
@@ -743,7 +756,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     if (a1_ahead) request(A1);
 
     if (SPLIT) {
-      float* ws = p.workspace + static_cast<long long>(blockIdx.y) * p.M * p.N;
+      float* ws = p.workspace + static_cast<long long>(split_idx) * p.M * p.N;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll

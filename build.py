@@ -130,11 +130,16 @@ def build_gpu(force=False, verbose=False, jobs_n=8):
     # packed forms issue slower than two plain instructions next to MFMAs.
     per_file = {"attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
     objs, cmds = [], []
+    draw_asm = None
     for s in kernels:
         o = BUILD / "gpu" / (s.stem + ".hip.o")
         objs.append(o)
         if _needs_build(s, o, hdr, force):
             cmds.append([hipcc, *kernel_flags, *per_file.get(s.name, []), "-c", s, "-o", o])
+            if s.name == "gemm_bf16.hip":
+                # the same translation unit once more as assembly, for the register check below
+                draw_asm = BUILD / "gpu" / "gemm_bf16.s"
+                cmds.append([hipcc, *kernel_flags, "--cuda-device-only", "-S", s, "-o", draw_asm])
     for s in torch_cpp:
         o = BUILD / "gpu" / (s.stem + ".cpp.o")
         objs.append(o)
@@ -149,6 +154,20 @@ def build_gpu(force=False, verbose=False, jobs_n=8):
     t0 = time.time()
     with cf.ThreadPoolExecutor(max_workers=max(1, jobs_n)) as ex:
         list(ex.map(lambda c: _run(c, verbose), cmds))
+    if draw_asm is not None:
+        # The streaming GEMM consumes the result of a returning atomic behind a counted wait, both in inline
+        # assembly: a build in which the compiler copies or spills the destination register in between reads a
+        # stale tile id (tools/check_draw_isa.py has the details).  Such a build must not ship.
+        sys.path.insert(0, str(ROOT / "tools"))
+        try:
+            import check_draw_isa
+        finally:
+            sys.path.pop(0)
+        problems = check_draw_isa.check(draw_asm.read_text())
+        if problems:
+            (BUILD / "gpu" / "gemm_bf16.hip.o").unlink(missing_ok=True)
+            raise RuntimeError("gemm_bf16.hip: the compiler touches the drawn tile id before it has arrived:\n  " + "\n  ".join(problems))
+        print("[build] gemm_bf16: drawn-tile-id register check ok", flush=True)
     stale = (not out.exists()) or any(o.stat().st_mtime > out.stat().st_mtime for o in objs)
     if cmds or stale:
         tlib = tdir / "lib"

@@ -571,7 +571,7 @@ def test_flash_attention_large_logits_and_causality():
     assert torch.count_nonzero(d[:, 130:].float()) == 0  # no gradient flows to later positions
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 384, 3), (4, 1024, 12)])
+@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 384, 3), (4, 1024, 12), (16, 1024, 2), (20, 1024, 1)])  # the last two: >= 512 partial rows (wide reduction kernel)
 def test_attention_backward_bias_gradient(B, T, H):
     """The column sums the backward kernels emit equal the sum over positions of the dqkv they wrote."""
     torch.manual_seed(T + H)

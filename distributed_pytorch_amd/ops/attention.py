@@ -8,8 +8,12 @@ direction, and the backward writes dq|dk|dv straight into one [B, T, 3*C] tensor
 gradient of the projection output).
 
 On gfx950 the work runs on hand-written flash-attention kernels (bf16 MFMA, online softmax,
-recompute-based backward without atomics) for head size 64 and T a multiple of 128; other
-shapes, dtypes and CPU tensors use torch's scaled-dot-product attention.
+recompute-based backward without atomics) for head size 64.  The kernels work on 128-row
+blocks: a sequence length that is not a multiple of 128 is zero-padded at the end up to the next
+block (padded keys lie in every real query's future, so the causal mask already hides them, and
+padded queries receive a zero output gradient, so they add nothing to dK / dV); the padded rows
+are cut off again on the way out.  Other head sizes, dtypes and CPU tensors use torch's
+scaled-dot-product attention.
 
 The reference contains no attention (its model is two linear layers, reference
 min_DDP.py:41-49); this op serves the GPT-2 benchmark configuration.
@@ -66,14 +70,21 @@ class _ProjFlashQKV(torch.autograd.Function):
         return dx, gemm.tn(g, x2, ctx.impl), db, None, None, None, None, None
 
 
-def native_attention_supported(qkv: torch.Tensor, n_head: int) -> bool:
-    if not (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.is_contiguous()):
+_BLOCK_ROWS = 128  # rows per query / key block of the kernels
+
+
+def native_attention_supported(qkv: torch.Tensor, n_head: int, pad_ok: bool = False) -> bool:
+    """True when the kernels take ``qkv`` as it is; with ``pad_ok`` also when they take it after the
+    sequence has been padded to a whole number of 128-row blocks."""
+    if not (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and (pad_ok or qkv.is_contiguous())):
         return False
     if not _ext.have_C():
         return False
     _, T, C3 = qkv.shape
-    if C3 % (3 * n_head):
+    if T <= 0 or C3 % (3 * n_head):
         return False
+    if pad_ok:
+        T += (-T) % _BLOCK_ROWS
     return bool(_ext.C().attention_supported(T, C3 // 3 // n_head, C3))
 
 
@@ -110,9 +121,13 @@ def causal_attention_qkvpacked(qkv: torch.Tensor, n_head: int, softmax_scale: Op
             qkv = qkv.to(torch.get_autocast_dtype("cuda"))
         if native_attention_supported(qkv, n_head):
             return _FlashQKV.apply(qkv, n_head, scale)
+        if native_attention_supported(qkv, n_head, pad_ok=True):
+            padded = F.pad(qkv, (0, 0, 0, (-T) % _BLOCK_ROWS))  # contiguous [B, T rounded up, 3*C], zero rows at the end
+            y = _FlashQKV.apply(padded, n_head, scale)
+            return y if padded.shape[1] == T else y[:, :T].contiguous()
         if impl == "native":
             raise RuntimeError(f"native attention does not cover qkv {tuple(qkv.shape)} {qkv.dtype} on {qkv.device} "
-                               f"with {n_head} heads (needs bf16, head size 64, T % 128 == 0, contiguous)")
+                               f"with {n_head} heads (needs bf16 and head size 64)")
     q, k, v = (t.view(B, T, n_head, hd).transpose(1, 2) for t in qkv.split(Cd, dim=2))
     y = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=scale)
     return y.transpose(1, 2).reshape(B, T, Cd)

@@ -626,12 +626,37 @@ def test_attention_op_autograd_and_fallback():
     (gs,) = torch.autograd.grad(ys, qkv_s, g)
     torch.testing.assert_close(y.float(), ys.float(), rtol=3e-2, atol=3e-2)
     torch.testing.assert_close(gn.float(), gs.float(), rtol=5e-2, atol=5e-2)
-    # unsupported shapes fall back (T not a multiple of 128) or raise when the native path is demanded
-    odd = torch.randn(1, 100, 3 * 64, device=DEV).bfloat16()
-    assert not native_attention_supported(odd, 1)
-    assert causal_attention_qkvpacked(odd, 1).shape == (1, 100, 64)
+    # unsupported head sizes fall back, or raise when the native path is demanded
+    odd = torch.randn(1, 128, 3 * 32, device=DEV).bfloat16()
+    assert not native_attention_supported(odd, 1) and not native_attention_supported(odd, 1, pad_ok=True)
+    assert causal_attention_qkvpacked(odd, 1).shape == (1, 128, 32)
     with pytest.raises(RuntimeError):
         causal_attention_qkvpacked(odd, 1, impl="native")
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 100, 2), (1, 129, 1), (3, 1000, 4), (2, 255, 3)])
+def test_attention_op_pads_sequences_to_whole_blocks(B, T, H):
+    """A sequence length that is not a multiple of the kernels' 128-row block runs on the native kernels
+    after zero padding: outputs and gradients of the real rows equal the fp32 reference, and a
+    non-contiguous (sliced) input is accepted."""
+    from distributed_pytorch_amd.ops.attention import causal_attention_qkvpacked, native_attention_supported
+
+    torch.manual_seed(T * 7 + H)
+    Cd = H * 64
+    scale = 1.0 / math.sqrt(64)
+    base = torch.randn(B, T + 3, 3 * Cd, device=DEV).bfloat16()
+    qkv = base[:, 3:].detach().requires_grad_()  # not contiguous
+    assert not native_attention_supported(qkv, H) and native_attention_supported(qkv, H, pad_ok=True)
+    y = causal_attention_qkvpacked(qkv, H, impl="native")
+    assert y.shape == (B, T, Cd) and y.is_contiguous()
+    (q, k, v), ref_o, _ = _attention_reference(qkv.detach(), H, scale)
+    torch.testing.assert_close(y.float(), ref_o, rtol=2e-2, atol=2e-2)
+    go = torch.randn_like(y)
+    (g,) = torch.autograd.grad(y, qkv, go)
+    ref_o.backward(go.float())
+    ref_g = torch.cat([t.grad.transpose(1, 2).reshape(B, T, Cd) for t in (q, k, v)], dim=2)
+    err = (g.float() - ref_g).abs().max().item()
+    assert g.shape == qkv.shape and err <= 1e-2 * ref_g.abs().max().item() + 1e-2, err
 
 
 @pytest.mark.parametrize("a_k,b_k", [(False, False), (True, True), (True, False)])

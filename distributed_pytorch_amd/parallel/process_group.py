@@ -429,6 +429,35 @@ def all_gather(t: torch.Tensor) -> List[torch.Tensor]:
     return outs
 
 
+def reduce_scatter(t: torch.Tensor, op=OP_SUM) -> torch.Tensor:
+    """Reduces ``t`` (first dimension divisible by the world size) over the ranks and returns this rank's
+    slice of the result, ``t.shape[0] // world`` rows: the first half of a ring all-reduce, for callers that
+    only need (or only want to update) their own shard.  One ``ncclReduceScatter`` on RCCL; gloo has no such
+    collective, so that path reduces the whole tensor and cuts the slice out."""
+    code = _to_op_code(op)
+    if _state is None or _state.world_size == 1:
+        return t
+    w, r = _state.world_size, _state.rank
+    if t.dim() == 0 or t.shape[0] % w:
+        raise ValueError(f"reduce_scatter: first dimension of {tuple(t.shape)} is not divisible by the world size {w}")
+    rows = t.shape[0] // w
+    progress_tick()
+    if _state.backend == "rccl":
+        s, cpu = _stage_for_rccl(t)
+        out = torch.empty((rows,) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device)
+        _state.comm.reduce_scatter(s, out, code)
+        if debug_sync():
+            torch.cuda.synchronize(s.device)
+        return out.cpu() if cpu is not None else out
+    full = t.clone()
+    if code == OP_AVG:
+        tdist.all_reduce(full, op=tdist.ReduceOp.SUM)
+        full /= w
+    else:
+        tdist.all_reduce(full, op=_to_c10d_op(code))
+    return full[r * rows:(r + 1) * rows].clone()
+
+
 def barrier() -> None:
     if _state is None or _state.world_size == 1:
         return

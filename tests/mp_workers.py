@@ -41,6 +41,18 @@ def collectives_worker(rank, world_size, out_dir):
     res["sync_params"] = p.tolist()
     red = dist.reduce(torch.tensor([2.0 + rank]), op=torch.distributed.ReduceOp.MAX)
     res["reduce_max"] = red.tolist()
+    from distributed_pytorch_amd.parallel import process_group as pg
+
+    res["all_gather"] = [x.tolist() for x in pg.all_gather(torch.tensor([rank, 10 + rank]))]
+    full = torch.arange(2 * world_size, dtype=torch.float32).reshape(2 * world_size, 1) * (rank + 1)
+    res["reduce_scatter_sum"] = pg.reduce_scatter(full).flatten().tolist()
+    res["reduce_scatter_avg"] = pg.reduce_scatter(full, "avg").flatten().tolist()
+    res["reduce_scatter_input_kept"] = bool(full[1, 0] == rank + 1)
+    try:
+        pg.reduce_scatter(torch.zeros(2 * world_size + 1))
+        res["reduce_scatter_bad"] = None
+    except ValueError as e:
+        res["reduce_scatter_bad"] = str(e)
     dist.barrier()
     dist.wait_for_everyone()
     s = dist.data_sampler(list(range(10)), True, shuffle=False)

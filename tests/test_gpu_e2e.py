@@ -45,6 +45,15 @@ def test_rccl_collectives_single_rank(rccl_group):
         x = torch.arange(17, device=DEV).to(dt)
         comm.all_reduce(x, 4 if dt.is_floating_point else 0)
         assert torch.equal(x, torch.arange(17, device=DEV).to(dt))
+    ag = torch.zeros(1, 1000, device=DEV)
+    comm.all_gather(t, ag)
+    assert torch.equal(ag[0], ref)
+    rs = torch.zeros(1000, device=DEV)
+    comm.reduce_scatter(t, rs, 0)
+    assert torch.equal(rs, ref)
+    with pytest.raises(RuntimeError):
+        comm.reduce_scatter(t, torch.zeros(999, device=DEV), 0)  # input must hold world * output elements
+    assert pg.reduce_scatter(t) is t and pg.all_gather(t)[0] is t  # one rank: nothing to exchange
     comm.barrier()
     # comm-stream path: fill on the compute stream, reduce on the comm stream, consume after wait
     bufs = [torch.zeros(1 << 20, device=DEV) for _ in range(4)]   # one bucket per slot, like the reducer

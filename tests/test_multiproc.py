@@ -42,6 +42,12 @@ def test_collectives_world2(tmp_path):
     assert r1["gather_bool"] == [[False, False], [False, False]]
     assert r0["sync_params"] == r1["sync_params"] == [0.0, 0.0, 0.0]
     assert r0["sampler"] == [0, 2, 4, 6, 8] and r1["sampler"] == [1, 3, 5, 7, 9]
+    # all_gather: every rank gets every rank's tensor; reduce_scatter: rank r gets rows r*n .. of the reduced tensor
+    assert r0["all_gather"] == r1["all_gather"] == [[0, 10], [1, 11]]
+    assert r0["reduce_scatter_sum"] == [0.0, 3.0] and r1["reduce_scatter_sum"] == [6.0, 9.0]  # arange(4) * (1 + 2)
+    assert r0["reduce_scatter_avg"] == [0.0, 1.5] and r1["reduce_scatter_avg"] == [3.0, 4.5]
+    assert r0["reduce_scatter_input_kept"] and r1["reduce_scatter_input_kept"]
+    assert "not divisible by the world size 2" in r0["reduce_scatter_bad"]
 
 
 def test_collectives_world3_sampler_padding(tmp_path):
@@ -49,6 +55,7 @@ def test_collectives_world3_sampler_padding(tmp_path):
     rs = _read(tmp_path, 3)
     assert rs[0]["reduce"] == [6.0, 60.0]
     assert rs[0]["gather"] == [[0, 0], [1, 2], [2, 4]]
+    assert [r["reduce_scatter_sum"] for r in rs] == [[0.0, 6.0], [12.0, 18.0], [24.0, 30.0]]  # arange(6) * (1 + 2 + 3)
     assert [r["sampler"] for r in rs] == [[0, 3, 6, 9], [1, 4, 7, 0], [2, 5, 8, 1]]  # padded with the head
 
 

@@ -51,6 +51,8 @@ def parse_args(argv=None):
     p.add_argument("--no-fuse-add-norm", action="store_true", help="GPT-2: separate residual adds and layer norms (ablation)")
     p.add_argument("--reduce-dtype", default=None, choices=["fp32", "bf16"], help="gradient all-reduce dtype")
     p.add_argument("--bucket-mb", type=float, default=None)
+    p.add_argument("--shard-optimizer", action="store_true",
+                   help="N > 1: every rank keeps optimizer state for, and updates, only the parameters it owns; owners broadcast the new values")
     p.add_argument("--no-busbw", action="store_true", help="skip the all-reduce bus-bandwidth measurement after the timed steps (N > 1)")
     p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
     p.add_argument("--force-ddp", action="store_true",
@@ -174,6 +176,10 @@ def run_rank(rank: int, world_size: int, argv):
         model = dist.prepare_ddp_model(model, device_ids=[device.index if device.type == "cuda" else None], **ddp_kwargs)
     if args.stock:
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, fused=use_gpu)
+    elif args.shard_optimizer:
+        from distributed_pytorch_amd.parallel import ShardedOptimizer
+
+        opt = ShardedOptimizer(model.parameters(), lr=1e-4, weight_decay=0.01, master_weights=(dtype != torch.float32))
     else:
         opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, master_weights=(dtype != torch.float32))
 
@@ -250,7 +256,8 @@ def run_rank(rank: int, world_size: int, argv):
             "seq_len": info["seq_len"],
             "parallelism": f"dp{n}",
             "params": info["params"],
-            "optimizer": "torch.optim.AdamW(fused)" if args.stock else "FusedAdamW" + ("+fp32-master" if dtype != torch.float32 else ""),
+            "optimizer": "torch.optim.AdamW(fused)" if args.stock else ("ShardedOptimizer(" if args.shard_optimizer else "") + "FusedAdamW"
+                         + ("+fp32-master" if dtype != torch.float32 else "") + (")" if args.shard_optimizer else ""),
             "stock_torch_ops": bool(args.stock),
             "linear_impl": args.linear_impl,
             "grad_reduce_dtype": (args.reduce_dtype or ("param dtype" if n > 1 else None)),

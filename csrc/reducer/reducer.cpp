@@ -69,30 +69,44 @@ class C10dTransport final : public Transport {
  public:
   explicit C10dTransport(c10::intrusive_ptr<c10d::ProcessGroup> pg) : pg_(std::move(pg)) {}
   bool native_average() const override { return false; }
-  // GPU tensors on a host-side group (gloo): the group stages them through pinned memory on streams of
-  // torch's pool, which first wait for an event of the compute stream.  With a long backlog on the compute
-  // stream (a real model's backward) that wait never returned on this runtime -- the stall described at
-  // RcclComm's own stream -- so the compute stream is drained first and the event is complete when waited on.
-  // This path is a plumbing configuration (several ranks sharing one GPU in tests), not a fast one.
-  static void drain_if_gpu(const at::Tensor& t) {
-    if (t.is_cuda()) c10::hip::getCurrentHIPStream(t.get_device()).synchronize();
+  // GPU tensors on a host-side group (gloo) are staged through host memory HERE, with plain synchronous copies on
+  // the current stream, and the group only ever sees CPU tensors.  Handing it the GPU tensor makes the group stage
+  // it itself on streams of torch's pool, with event waits between those streams and the compute stream in both
+  // directions; on this runtime such a wait on an event the other stream has not reached yet has been seen never to
+  // return (the stall described at RcclComm's own stream): with a real model's backlog on the compute stream always,
+  // with a short backward and two ranks sharing the GPU about every other run.  This path is a plumbing
+  // configuration (several ranks sharing one GPU in tests), not a fast one, so nothing is overlapped.
+  static void reduce_through_host(c10d::ProcessGroup& pg, at::Tensor& t) {
+    at::Tensor h = t.to(at::kCPU);  // device-to-host copy; returns when the data is there
+    std::vector<at::Tensor> ts{h};
+    c10d::AllreduceOptions o;
+    o.reduceOp = c10d::ReduceOp::SUM;
+    pg.allreduce(ts, o)->wait();
+    t.copy_(h);
   }
   void all_reduce_async(at::Tensor flat, int /*slot*/, bool /*average: pre-divided by the reducer*/) override {
-    drain_if_gpu(flat);
+    if (flat.is_cuda()) {
+      reduce_through_host(*pg_, flat);
+      return;
+    }
     std::vector<at::Tensor> ts{flat};
     c10d::AllreduceOptions o;
     o.reduceOp = c10d::ReduceOp::SUM;
     works_.push_back(pg_->allreduce(ts, o));
   }
   void broadcast(at::Tensor flat, int root) override {
-    drain_if_gpu(flat);
-    std::vector<at::Tensor> ts{flat};
+    at::Tensor h = flat.is_cuda() ? flat.to(at::kCPU) : flat;
+    std::vector<at::Tensor> ts{h};
     c10d::BroadcastOptions o;
     o.rootRank = root;
     pg_->broadcast(ts, o)->wait();
+    if (flat.is_cuda() && pg_->getRank() != root) flat.copy_(h);
   }
   void all_reduce_sum_blocking(at::Tensor t) override {
-    drain_if_gpu(t);
+    if (t.is_cuda()) {
+      reduce_through_host(*pg_, t);
+      return;
+    }
     std::vector<at::Tensor> ts{t};
     c10d::AllreduceOptions o;
     o.reduceOp = c10d::ReduceOp::SUM;

@@ -55,6 +55,9 @@ class FusedAdamW(Optimizer):
         super().__init__(params, defaults)
         self.master_weights = bool(master_weights)
         self.max_grad_norm = max_grad_norm
+        # Parameters whose gradients define the global norm for clipping; None = this optimizer's own.  A sharded
+        # optimizer that updates a subset of the model sets it to all parameters (parallel/zero.py).
+        self.clip_params: Optional[List[torch.Tensor]] = None
         # Device-side hyper-parameters + step counter, one float32[8] per (group, cohort).  A cohort is the set
         # of a group's parameters that share a step count; its key is the group's tick count minus that step
         # count, which stays constant for a parameter's whole life: 0 for parameters updated from the first
@@ -130,6 +133,7 @@ class FusedAdamW(Optimizer):
                 loss = closure()
 
         gpu_groups = []
+        cpu_scale = None
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -139,14 +143,17 @@ class FusedAdamW(Optimizer):
             if ps[0].is_cuda:
                 gpu_groups.append((gi, group, ps))
             else:
-                self._step_cpu(group, ps)
+                if cpu_scale is None:
+                    cpu_scale = self._cpu_clip_scale()
+                self._step_cpu(group, ps, cpu_scale)
 
         if not gpu_groups:
             return loss
         C = _ext.C()
         grad_scale = None
         if self.max_grad_norm is not None:
-            grad_scale = self._clip_coefficient(C, [p.grad for _, _, ps in gpu_groups for p in ps])
+            over = self.clip_params if self.clip_params is not None else [p for _, _, ps in gpu_groups for p in ps]
+            grad_scale = self._clip_coefficient(C, [p.grad for p in over if p.grad is not None and p.is_cuda])
         for gi, group, ps in gpu_groups:
             states = [self._init_state(p) for p in ps]
             ticks = self._ticks.get(gi, 0)
@@ -189,14 +196,18 @@ class FusedAdamW(Optimizer):
         self.last_grad_norm = c["norm"]
         return c["coef"]
 
-    def _step_cpu(self, group: dict, ps: List[torch.Tensor]) -> None:
+    def _cpu_clip_scale(self) -> float:
+        """Clip coefficient of the CPU path: one global norm over all groups (or ``clip_params``)."""
+        if self.max_grad_norm is None:
+            return 1.0
+        over = self.clip_params if self.clip_params is not None else [p for g in self.param_groups for p in g["params"]]
+        norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in over if p.grad is not None and not p.is_cuda))
+        self.last_grad_norm = norm
+        return float(min(1.0, self.max_grad_norm / (norm + 1e-6)))
+
+    def _step_cpu(self, group: dict, ps: List[torch.Tensor], scale: float = 1.0) -> None:
         """Reference arithmetic on CPU tensors (the CPU oracle path): identical formula."""
         lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
-        scale = 1.0
-        if self.max_grad_norm is not None:
-            norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in ps))
-            self.last_grad_norm = norm
-            scale = float(min(1.0, self.max_grad_norm / (norm + 1e-6)))
         for p in ps:
             st = self._init_state(p)
             st["step"] += 1
@@ -219,9 +230,11 @@ class FusedAdamW(Optimizer):
         self._hparams_host.clear()
         self._ticks.clear()
         self._step_i.clear()
+        # torch hands tensors that already have the right dtype / device over as they are: cloned here, so that this
+        # optimizer never updates the tensors of the dict it was loaded from (a live optimizer's state_dict()).
         for st in self.state.values():
             if "step" in st and torch.is_tensor(st["step"]):
-                st["step"] = st["step"].detach().to("cpu", torch.float32)
+                st["step"] = st["step"].detach().to("cpu", torch.float32).clone()
             for k in ("exp_avg", "exp_avg_sq", "master"):
                 if k in st:
-                    st[k] = st[k].to(torch.float32)
+                    st[k] = st[k].to(torch.float32, copy=True)

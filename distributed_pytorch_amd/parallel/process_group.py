@@ -341,6 +341,14 @@ def _finish(staged: torch.Tensor, original_cpu: Optional[torch.Tensor], user: to
         torch.cuda.synchronize(staged.device)
 
 
+def _host_copy(t: torch.Tensor) -> torch.Tensor:
+    """gloo only ever sees CPU tensors: a GPU tensor is copied to the host here (a synchronous copy on the
+    current stream) and the result copied back by the caller.  Given the GPU tensor itself, the group stages it
+    on side streams that exchange event waits with the compute stream, and on this runtime such a wait on an
+    event the other stream has not reached yet has been seen never to return."""
+    return t.cpu() if t.is_cuda else t
+
+
 # ------------------------------------------------------------------------------ collectives
 def all_reduce(t: torch.Tensor, op=OP_SUM) -> torch.Tensor:
     code = _to_op_code(op)
@@ -352,11 +360,14 @@ def all_reduce(t: torch.Tensor, op=OP_SUM) -> torch.Tensor:
         _state.comm.all_reduce(s, code)
         _finish(s, cpu, t)
     else:
+        h = _host_copy(t)
         if code == OP_AVG:  # gloo has no AVG
-            tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
-            t /= _state.world_size
+            tdist.all_reduce(h, op=tdist.ReduceOp.SUM)
+            h /= _state.world_size
         else:
-            tdist.all_reduce(t, op=_to_c10d_op(code))
+            tdist.all_reduce(h, op=_to_c10d_op(code))
+        if h is not t:
+            t.copy_(h)
     return t
 
 
@@ -370,7 +381,10 @@ def reduce(t: torch.Tensor, dst: int = 0, op=OP_SUM) -> torch.Tensor:
         _state.comm.reduce(s, int(dst), code)
         _finish(s, cpu, t)
     else:
-        tdist.reduce(t, dst=dst, op=_to_c10d_op(code))
+        h = _host_copy(t)
+        tdist.reduce(h, dst=dst, op=_to_c10d_op(code))
+        if h is not t and _state.rank == dst:
+            t.copy_(h)
     return t
 
 
@@ -383,7 +397,10 @@ def broadcast(t: torch.Tensor, src: int = 0) -> torch.Tensor:
         _state.comm.broadcast(s, int(src))
         _finish(s, cpu, t)
     else:
-        tdist.broadcast(t, src)
+        h = _host_copy(t)
+        tdist.broadcast(h, src)
+        if h is not t and _state.rank != src:
+            t.copy_(h)
     return t
 
 
@@ -404,12 +421,13 @@ def gather(t: torch.Tensor, dst: int = 0) -> List[torch.Tensor]:
         if cpu is not None:
             out = out.cpu()
         return list(out.unbind(0))
-    outs = [torch.zeros_like(t) for _ in range(w)]
+    h = _host_copy(t)
+    outs = [torch.zeros_like(h) for _ in range(w)]
     if _state.rank == dst:
-        tdist.gather(t, gather_list=outs, dst=dst)
+        tdist.gather(h, gather_list=outs, dst=dst)
     else:
-        tdist.gather(t, dst=dst)
-    return outs
+        tdist.gather(h, dst=dst)
+    return [o.to(t.device) for o in outs] if h is not t else outs
 
 
 def all_gather(t: torch.Tensor) -> List[torch.Tensor]:
@@ -424,9 +442,10 @@ def all_gather(t: torch.Tensor) -> List[torch.Tensor]:
         if cpu is not None:
             out = out.cpu()
         return list(out.unbind(0))
-    outs = [torch.empty_like(t) for _ in range(w)]
-    tdist.all_gather(outs, t)
-    return outs
+    h = _host_copy(t)
+    outs = [torch.empty_like(h) for _ in range(w)]
+    tdist.all_gather(outs, h)
+    return [o.to(t.device) for o in outs] if h is not t else outs
 
 
 def reduce_scatter(t: torch.Tensor, op=OP_SUM) -> torch.Tensor:
@@ -449,13 +468,13 @@ def reduce_scatter(t: torch.Tensor, op=OP_SUM) -> torch.Tensor:
         if debug_sync():
             torch.cuda.synchronize(s.device)
         return out.cpu() if cpu is not None else out
-    full = t.clone()
+    full = t.cpu() if t.is_cuda else t.clone()
     if code == OP_AVG:
         tdist.all_reduce(full, op=tdist.ReduceOp.SUM)
         full /= w
     else:
         tdist.all_reduce(full, op=_to_c10d_op(code))
-    return full[r * rows:(r + 1) * rows].clone()
+    return full[r * rows:(r + 1) * rows].to(t.device, copy=True)
 
 
 def barrier() -> None:

@@ -295,3 +295,91 @@ def ddp_unused_worker(rank, world_size, out_dir):
     res["in_sync"] = model.check_replicas_in_sync()
     _dump(out_dir, rank, res)
     dist.cleanup()
+
+
+class _ConvNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 8, 3, padding=1)
+        self.fc1 = nn.Linear(8, 32)
+        self.fc2 = nn.Linear(32, 5)
+
+    def forward(self, x):
+        return self.fc2(torch.relu(self.fc1(torch.relu(self.conv(x)).mean((2, 3)))))
+
+
+def sharded_optimizer_worker(rank, world_size, out_dir):
+    """Sharded optimizer state (each rank updates the parameters it owns and publishes them) must walk the same
+    path as a full optimizer on every rank, clip by the same global norm, and hand its state over through the
+    unsharded layout."""
+    import distributed as dist
+    from distributed_pytorch_amd.ops import FusedAdamW
+    from distributed_pytorch_amd.parallel import ShardedOptimizer
+    from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+    dist.init_process_group(rank, world_size, "gloo")
+
+    def make():
+        torch.manual_seed(5)
+        m = _ConvNet()
+        m.conv.weight.data = m.conv.weight.data.contiguous(memory_format=torch.channels_last)  # a parameter that cannot be re-homed as a flat view
+        return m
+
+    full_m, shard_m = make(), make()
+    full = DistributedDataParallel(full_m)
+    shard = DistributedDataParallel(shard_m)
+    groups = lambda m: [{"params": [p for n, p in m.named_parameters() if n.endswith("weight")], "weight_decay": 0.1},
+                        {"params": [p for n, p in m.named_parameters() if n.endswith("bias")], "weight_decay": 0.0}]
+    o_full = FusedAdamW(groups(full_m), lr=1e-2, max_grad_norm=0.5)
+    o_shard = ShardedOptimizer(groups(shard_m), lr=1e-2, max_grad_norm=0.5)
+    res = {"owner": o_shard.owner, "load": o_shard.shard_numel(),
+           "rehomed": [bool(re) for _, _, entries in o_shard._shards for _, _, re in entries]}
+    g = torch.Generator().manual_seed(11 + rank)
+
+    def run(n, pairs):
+        for step in range(n):
+            x = torch.randn(6, 3, 8, 8, generator=g)
+            y = torch.randint(0, 5, (6,), generator=g)
+            for m, o in pairs:
+                o.zero_grad()
+                nn.functional.cross_entropy(m(x), y).backward()
+                o.step()
+
+    def max_diff(a, b):
+        return max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(a.parameters(), b.parameters()))
+
+    run(3, ((full, o_full), (shard, o_shard)))
+    res["diff_after_3"] = max_diff(full_m, shard_m)
+    res["grad_norm_equal"] = bool(o_shard.last_grad_norm is None or torch.equal(o_shard.last_grad_norm, o_full.last_grad_norm))
+    res["state_entries"] = len(o_shard.inner.state) if o_shard.inner is not None else 0
+    res["owned"] = len(o_shard._owned_global)
+    for grp in o_shard.param_groups:  # a schedule written into the outer groups reaches the inner optimizer
+        grp["lr"] = 5e-3
+    for grp in o_full.param_groups:
+        grp["lr"] = 5e-3
+    run(2, ((full, o_full), (shard, o_shard)))
+    res["diff_after_5"] = max_diff(full_m, shard_m)
+    # unsharded layout: equals the full optimizer's state, loads into a plain optimizer and into a fresh sharded one
+    cons = o_shard.consolidated_state_dict()
+    ref_sd = o_full.state_dict()
+    res["cons_keys_equal"] = sorted(cons["state"].keys()) == sorted(ref_sd["state"].keys())
+    res["cons_state_diff"] = max(float((cons["state"][k][f] - ref_sd["state"][k][f]).abs().max())
+                                 for k in ref_sd["state"] for f in ("exp_avg", "exp_avg_sq", "step"))
+    res["cons_groups_equal"] = [{k: v for k, v in grp.items()} for grp in cons["param_groups"]] == \
+                               [{k: v for k, v in grp.items()} for grp in ref_sd["param_groups"]]
+    plain_m, again_m = make(), make()
+    plain_m.load_state_dict(shard_m.state_dict())
+    again_m.load_state_dict(shard_m.state_dict())
+    plain, again = DistributedDataParallel(plain_m), DistributedDataParallel(again_m)
+    o_plain = FusedAdamW(groups(plain_m), lr=1e-2, max_grad_norm=0.5)
+    o_plain.load_state_dict(cons)
+    o_again = ShardedOptimizer(groups(again_m), lr=1e-2, max_grad_norm=0.5)
+    o_again.load_state_dict(cons)
+    res["lr_restored"] = [grp["lr"] for grp in o_again.param_groups]
+    own = o_shard.state_dict()
+    o_shard.load_state_dict(own)  # a rank's own shard format round-trips
+    run(2, ((full, o_full), (shard, o_shard), (plain, o_plain), (again, o_again)))
+    res["diff_after_resume"] = max(max_diff(full_m, shard_m), max_diff(full_m, plain_m), max_diff(full_m, again_m))
+    res["in_sync"] = shard.check_replicas_in_sync()
+    _dump(out_dir, rank, res)
+    dist.cleanup()

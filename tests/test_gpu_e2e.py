@@ -448,6 +448,34 @@ def test_full_size_gpt2_two_ranks_on_one_gpu_over_gloo():
     assert r["final_loss"] < r["first_loss"]
 
 
+def test_sharded_optimizer_two_ranks_on_one_gpu_equals_full_optimizer():
+    """bf16 GPT-2 under the reducer on two ranks sharing the GPU (gloo): with the optimizer state sharded by
+    parameter ownership (flat device buffers the owned parameters live in, fp32 master weights on the owner only,
+    one broadcast per owner) the run ends on the same loss, digit for digit, as with a full optimizer per rank."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ)
+    env["PYTHONPATH"] = str(root) + os.pathsep + env.get("PYTHONPATH", "")
+    env["HIP_VISIBLE_DEVICES"] = "0"
+    env["DIST_ALLOW_GPU_SHARING"] = "1"
+    runs = []
+    for extra in ([], ["--shard-optimizer"]):
+        p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch-size", "2", "--seq-len", "256",
+                            "--steps", "4", "--warmup", "2"] + extra, cwd=str(root), env=env, timeout=110, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout[-3000:]
+        runs.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1]))
+    full, sharded = runs
+    assert sharded["config"]["optimizer"].startswith("ShardedOptimizer(") and not full["config"]["optimizer"].startswith("Sharded")
+    assert sharded["first_loss"] == full["first_loss"] and sharded["final_loss"] == full["final_loss"]
+    assert sharded["final_loss"] < sharded["first_loss"]
+    assert sharded["peak_mem_gb"] < full["peak_mem_gb"]  # half of the master weights and moments per rank
+
+
 def test_rccl_group_through_torch_distributed_run_store():
     """The rendezvous path of the multi-GPU benchmark (torch.distributed.run hosts the store on
     MASTER_PORT, the ncclUniqueId travels through it), at the world size one GPU allows."""

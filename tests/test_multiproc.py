@@ -308,3 +308,19 @@ def test_find_unused_parameters_keeps_globally_unused_grads_none(tmp_path):
         assert r["globally_unused"] == [4, 5]                      # never.weight, never.bias
         # rank 0 contributes ones * 2 rows = 2 per output, rank 1 zeros: average 1
         assert r["rank0_only_bias_grad"] == [1.0, 1.0, 1.0, 1.0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_matches_full_optimizer(tmp_path, world):
+    dist.launch(mp_workers.sharded_optimizer_worker, str(tmp_path), nprocs=world)
+    rs = _read(tmp_path, world)
+    for r in rs:
+        assert r["owner"] == rs[0]["owner"] and sorted(set(r["owner"])) == list(range(world))
+        assert max(r["load"]) < 0.75 * sum(r["load"])              # no rank owns (nearly) everything
+        assert False in r["rehomed"] and True in r["rehomed"]      # the channels-last weight is copied, the rest are flat views
+        assert r["state_entries"] == r["owned"] < 6                # optimizer state exists for owned parameters only
+        assert r["diff_after_3"] == 0.0 and r["diff_after_5"] == 0.0 and r["diff_after_resume"] == 0.0
+        assert r["grad_norm_equal"] and r["in_sync"]
+        assert r["cons_keys_equal"] and r["cons_state_diff"] == 0.0 and r["cons_groups_equal"]
+        assert r["lr_restored"] == [5e-3, 5e-3]
+    assert sum(r["owned"] for r in rs) == 6

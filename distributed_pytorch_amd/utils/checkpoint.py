@@ -39,11 +39,17 @@ def _match_layout(state: Dict[str, Any], model: torch.nn.Module) -> Dict[str, An
 
 def save_checkpoint(path: str, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer] = None, step: int = 0,
                     extra: Optional[dict] = None) -> None:
-    """Rank 0 writes atomically (temp file + rename); all ranks leave together."""
+    """Rank 0 writes atomically (temp file + rename); all ranks leave together.  An optimizer whose state is
+    sharded over the ranks (``consolidated_state_dict``, collective) is saved in the unsharded layout, so the
+    file loads on any world size and into a plain optimizer."""
+    opt_state = None
+    if optimizer is not None:
+        gather = getattr(optimizer, "consolidated_state_dict", None)
+        opt_state = gather() if gather is not None else (optimizer.state_dict() if pg.get_rank() == 0 else None)
     if pg.get_rank() == 0:
         payload = {
             "model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-            "optimizer": optimizer.state_dict() if optimizer is not None else None,
+            "optimizer": opt_state,
             "step": int(step),
             "world_size": pg.get_world_size(),
             "extra": extra or {},

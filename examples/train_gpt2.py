@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import distributed as dist  # noqa: E402
 from distributed_pytorch_amd.models import GPT2, GPT2Config  # noqa: E402
 from distributed_pytorch_amd.ops import FusedAdamW  # noqa: E402
+from distributed_pytorch_amd.parallel import ShardedOptimizer  # noqa: E402
 from distributed_pytorch_amd.utils.checkpoint import load_checkpoint, save_checkpoint  # noqa: E402
 from distributed_pytorch_amd.utils.data import DevicePrefetcher  # noqa: E402
 from distributed_pytorch_amd.utils.debug import assert_in_sync  # noqa: E402
@@ -66,6 +67,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--resume", action="store_true", help="continue from --ckpt if it exists")
     p.add_argument("--log", default=None, help="JSONL log path (default: stdout of the primary rank)")
     p.add_argument("--log-every", type=int, default=10)
+    p.add_argument("--shard-optimizer", action="store_true",
+                   help="keep master weights and moments only for the parameters this rank owns (1/N of the optimizer state per GPU)")
     return p
 
 
@@ -80,7 +83,8 @@ def main_worker(gpu, world_size, argv=None):
     cfg = GPT2Config(block_size=args.seq_len, vocab_size=args.vocab_size, n_layer=args.n_layer, n_head=args.n_head, n_embd=args.n_embd)
     model = GPT2(cfg).to(device=device, dtype=torch.bfloat16 if on_gpu else torch.float32)
     model = dist.prepare_ddp_model(model, device_ids=[gpu])
-    opt = FusedAdamW(model.parameters(), lr=args.lr, weight_decay=0.1, master_weights=on_gpu, max_grad_norm=1.0)
+    make_opt = ShardedOptimizer if args.shard_optimizer else FusedAdamW
+    opt = make_opt(model.parameters(), lr=args.lr, weight_decay=0.1, master_weights=on_gpu, max_grad_norm=1.0)
 
     step = 0
     if args.resume and args.ckpt and os.path.exists(args.ckpt):

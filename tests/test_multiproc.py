@@ -235,6 +235,21 @@ def test_example_training_script_two_ranks_checkpoint_and_resume(tmp_path):
     assert "resumed from" in second.stdout and "at step 8" in second.stdout
     recs2 = [json.loads(ln) for ln in second.stdout.splitlines() if ln.startswith("{")]
     assert [r["step"] for r in recs2] == [12]
+    # the checkpoint of the full optimizer continues under the sharded one, whose checkpoint (unsharded layout,
+    # assembled from both ranks' shards) continues under the full one again
+    third = subprocess.run(base + ["--steps", "16", "--resume", "--shard-optimizer"], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert third.returncode == 0, third.stderr[-2000:]
+    assert "at step 12" in third.stdout and "saved" in third.stdout
+    import torch
+
+    saved = torch.load(ckpt, weights_only=True)
+    n_params = len([k for k in saved["model"] if not k.endswith("lm_head.weight")])
+    assert saved["step"] == 16 and len(saved["optimizer"]["state"]) == n_params  # state of every parameter, from both shards
+    fourth = subprocess.run(base + ["--steps", "20", "--resume"], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert fourth.returncode == 0, fourth.stderr[-2000:]
+    recs4 = [json.loads(ln) for ln in fourth.stdout.splitlines() if ln.startswith("{")]
+    assert "at step 16" in fourth.stdout and [r["step"] for r in recs4] == [20]
+    assert recs4[-1]["loss"] < recs[0]["loss"]
 
 
 def test_bucket_rebuild_slicing_and_positional_args(tmp_path):

@@ -218,7 +218,7 @@ def run_rank(rank: int, world_size: int, argv):
     for i in range(args.warmup):
         l = step()
         if i == 0:
-            first_loss = l
+            first_loss = l.detach().clone() if l is not None else None  # a graph replay rewrites its output tensor in place
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -185,6 +185,38 @@ def _verify_devices(C, st: Store, state: "_State", dev: torch.device) -> None:
         raise RuntimeError(f"init_process_group: {verdict}")
 
 
+_INIT_HINT = ("check the rank->GPU map printed above; HSA_ENABLE_IPC_MODE_LEGACY=%s here (hosts whose driver only supports "
+              "dmabuf IPC need it exported as 0, or peer-memory handles fail with 'hipIpcGetMemHandle: invalid argument'); "
+              "NCCL_DEBUG=INFO shows the transport RCCL chose")
+
+
+def guarded_call(fn, timeout_s: float, what: str, on_timeout=None):
+    """Runs ``fn()`` (a blocking native call that has released the GIL) under a deadline.  Communicator
+    creation is a rendezvous of all ranks inside the library: when it never returns, no rank reaches the
+    store barrier or starts its heartbeat, so nothing else would ever end the job.  On expiry a line
+    saying what was being waited for is written and the process exits with status 87."""
+    import threading
+
+    done = threading.Event()
+
+    def expire():
+        if done.is_set():
+            return
+        sys.stderr.write(f"[rank {os.environ.get('RANK', '?')}] {what} did not return within {timeout_s:.0f} s; "
+                         + _INIT_HINT % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>") + "\n")
+        sys.stderr.flush()
+        (on_timeout or (lambda: os._exit(87)))()
+
+    timer = threading.Timer(timeout_s, expire)
+    timer.daemon = True
+    timer.start()
+    try:
+        return fn()
+    finally:
+        done.set()
+        timer.cancel()
+
+
 # ------------------------------------------------------------------------------ lifecycle
 def init_process_group(rank: int, world_size: int, backend: Optional[str] = None, *, timeout_s: Optional[float] = None, store: Optional[Store] = None) -> None:
     global _state
@@ -222,7 +254,11 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
             st.set(key, C.RcclComm.unique_id())
         uid = st.get(key, timeout_s)
         # Communicator is created eagerly so that iteration 0 does not pay for it.
-        state.comm = C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0)
+        try:
+            state.comm = guarded_call(lambda: C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0),
+                                      timeout_s, f"ncclCommInitRank (rank {rank} of {world_size})")
+        except RuntimeError as exc:
+            raise RuntimeError(f"{exc}\n  " + _INIT_HINT % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>")) from exc
         state.comm.set_debug_sync(debug_sync())
     else:
         state.device = torch.device("cpu") if not torch.cuda.is_available() else torch.device(f"cuda:{local_device_index(rank)}")

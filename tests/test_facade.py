@@ -280,6 +280,28 @@ def test_device_uniqueness_check():
     assert format_device_map(ok).startswith("[rccl] rank->GPU (PCI bus id): 0->0000:05:00.0, 1->0000:15:00.0")
 
 
+def test_guarded_call_deadline(capsys):
+    """Communicator creation runs under a deadline: a call that returns in time passes its value (or its
+    exception) through, one that does not gets a line naming what was waited for and the exit hook."""
+    import threading
+    import time
+
+    from distributed_pytorch_amd.parallel.process_group import guarded_call
+
+    assert guarded_call(lambda: 41 + 1, 5.0, "quick call") == 42
+    with pytest.raises(ValueError):
+        guarded_call(lambda: (_ for _ in ()).throw(ValueError("boom")), 5.0, "failing call")
+    fired = threading.Event()
+    guarded_call(lambda: time.sleep(0.6), 0.2, "ncclCommInitRank (rank 0 of 8)", on_timeout=fired.set)
+    assert fired.is_set()
+    err = capsys.readouterr().err
+    assert "ncclCommInitRank (rank 0 of 8) did not return within 0 s" in err and "HSA_ENABLE_IPC_MODE_LEGACY" in err
+    fired.clear()
+    guarded_call(lambda: None, 0.1, "returns at once", on_timeout=fired.set)
+    time.sleep(0.3)
+    assert not fired.is_set()  # the timer is disarmed when the call returns
+
+
 def test_launcher_leaves_ipc_mode_alone(monkeypatch):
     """Runtime variables that change how peer mappings are opened reach the workers as exported,
     never invented by the launcher."""

@@ -377,7 +377,9 @@ def main():
     # is stuck as a whole (e.g. inside its very first collective) and the hang monitor should end it with a
     # message instead of leaving it to the caller's time limit.  (The monitor's default only acts on a rank that
     # falls behind its peers, because a long phase without collectives is legitimate in general.)
-    os.environ.setdefault("DIST_STALL_TIMEOUT_S", "300")
+    # Not for ResNet-50: the convolution library's first-run kernel search can take minutes without a collective.
+    if args.model != "resnet50":
+        os.environ.setdefault("DIST_STALL_TIMEOUT_S", "300")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world not in (None, ""):  # started by torchrun (or any launcher exporting the rendezvous env)
         run_rank(int(os.environ.get("RANK", "0")), int(env_world), argv)

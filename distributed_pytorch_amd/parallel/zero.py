@@ -42,21 +42,17 @@ def partition_by_size(sizes: Sequence[int], world: int) -> List[int]:
     return owner
 
 
-class ShardedOptimizer:
+class ShardedOptimizer(torch.optim.Optimizer):
+    """An ``Optimizer`` to the outside (``param_groups`` hold ALL parameters, so learning-rate schedulers and
+    ``zero_grad`` work as usual); the state lives in the inner optimizer over the owned parameters."""
+
     def __init__(self, params: Iterable, optimizer_class=None, *, max_grad_norm: Optional[float] = None,
                  flatten: bool = True, **defaults):
         from ..ops import FusedAdamW
 
         self.optimizer_class = optimizer_class or FusedAdamW
-        groups = list(params)
-        if not groups:
-            raise ValueError("optimizer got an empty parameter list")
-        if not isinstance(groups[0], dict):
-            groups = [{"params": groups}]
-        self.param_groups: List[Dict[str, Any]] = [{**g, "params": list(g["params"])} for g in groups]
+        super().__init__(params, dict(defaults))  # validates the groups (duplicates, empty list) and fills in the given defaults
         self._all: List[torch.Tensor] = [p for g in self.param_groups for p in g["params"]]
-        if len({id(p) for p in self._all}) != len(self._all):
-            raise ValueError("some parameters appear in more than one parameter group")
         self.world = pg.get_world_size() if pg.is_initialized() else 1
         self.rank = pg.get_rank() if self.world > 1 else 0
         self.owner = partition_by_size([p.numel() for p in self._all], self.world)
@@ -126,16 +122,6 @@ class ShardedOptimizer:
         return load
 
     # ------------------------------------------------------------------ step
-    def zero_grad(self, set_to_none: bool = True) -> None:
-        for p in self._all:
-            if p.grad is None:
-                continue
-            if set_to_none:
-                p.grad = None
-            else:
-                p.grad.detach_()
-                p.grad.zero_()
-
     def _sync_hparams(self) -> None:
         if self.inner is None:
             return

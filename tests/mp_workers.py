@@ -353,10 +353,8 @@ def sharded_optimizer_worker(rank, world_size, out_dir):
     res["grad_norm_equal"] = bool(o_shard.last_grad_norm is None or torch.equal(o_shard.last_grad_norm, o_full.last_grad_norm))
     res["state_entries"] = len(o_shard.inner.state) if o_shard.inner is not None else 0
     res["owned"] = len(o_shard._owned_global)
-    for grp in o_shard.param_groups:  # a schedule written into the outer groups reaches the inner optimizer
-        grp["lr"] = 5e-3
-    for grp in o_full.param_groups:
-        grp["lr"] = 5e-3
+    for o in (o_full, o_shard):  # a scheduler drives the outer groups; the inner optimizer follows at the next step
+        torch.optim.lr_scheduler.StepLR(o, step_size=1, gamma=0.5).step()
     run(2, ((full, o_full), (shard, o_shard)))
     res["diff_after_5"] = max_diff(full_m, shard_m)
     # unsharded layout: equals the full optimizer's state, loads into a plain optimizer and into a fresh sharded one

@@ -273,10 +273,11 @@ def run_rank(rank: int, world_size: int, argv):
         result["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
         result["peak_reserved_gb"] = round(torch.cuda.max_memory_reserved(device) / 2**30, 2)
     bail = None
-    if use_gpu and on_rccl and not args.no_busbw:
-        # The extras below are collective: a rank that fails inside one of them leaves the others waiting.  Every
-        # rank therefore arms a deadline; when it passes, rank 0 prints the line it already has and all ranks
-        # leave without tearing the communicator down.
+    rccl_extras = use_gpu and on_rccl and not args.no_busbw
+    if world_size > 1 or rccl_extras:
+        # Everything below is collective and runs after the timed region: a rank that fails inside it leaves the
+        # others waiting.  Every rank therefore arms a deadline; when it passes, rank 0 prints the line it already
+        # has and all ranks leave without tearing the communicator down.
         import threading
 
         def _give_up():
@@ -289,7 +290,15 @@ def run_rank(rank: int, world_size: int, argv):
         bail = threading.Timer(extras_deadline, _give_up)
         bail.daemon = True
         bail.start()
-        # After the timed region, never allowed to cost the result line:
+    if world_size > 1 and hasattr(model, "check_replicas_in_sync"):
+        # Every rank's parameters must still be bit-identical (same averaged gradients, same update), which is what
+        # a stream-ordering or bucket-layout bug in the data-parallel path would break.
+        try:
+            result["replicas_in_sync"] = bool(model.check_replicas_in_sync())
+        except Exception as exc:  # noqa: BLE001 - diagnostic extra only
+            result["replicas_in_sync"] = f"failed: {type(exc).__name__}: {exc}"
+    if rccl_extras:
+        # Never allowed to cost the result line:
         #  * overlap accounting over three extra steps: run time of the bucket all-reduces on the communication
         #    stream and how much of it the compute stream had to wait for (the part backward did not hide);
         #  * all-reduce bus bandwidth over bucket-sized messages, on the reducer's own path (communication

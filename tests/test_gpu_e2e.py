@@ -445,6 +445,7 @@ def test_full_size_gpt2_two_ranks_on_one_gpu_over_gloo():
     assert p.returncode == 0, p.stdout[-3000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 2 and r["config"]["model"] == "gpt2-small" and r["config"]["comm"] == "gloo"
+    assert r["replicas_in_sync"] is True
     assert r["final_loss"] < r["first_loss"]
 
 
@@ -473,6 +474,7 @@ def test_sharded_optimizer_two_ranks_on_one_gpu_equals_full_optimizer():
     assert sharded["config"]["optimizer"].startswith("ShardedOptimizer(") and not full["config"]["optimizer"].startswith("Sharded")
     assert sharded["first_loss"] == full["first_loss"] and sharded["final_loss"] == full["final_loss"]
     assert sharded["final_loss"] < sharded["first_loss"]
+    assert sharded["replicas_in_sync"] is True and full["replicas_in_sync"] is True
     assert sharded["peak_mem_gb"] < full["peak_mem_gb"]  # half of the master weights and moments per rank
 
 

@@ -215,6 +215,7 @@ def test_bench_under_torch_distributed_run_two_ranks():
     rec = json.loads(lines[0])
     assert rec["steps"] == 2 and rec["warmup"] == 1 and rec["config"]["parallelism"] == "dp2"
     assert rec["config"]["global_batch"] == 512 and rec["config"]["comm"] == "gloo" and rec["value"] > 0
+    assert rec["replicas_in_sync"] is True  # parameter checksums of the ranks compared after the timed steps
 
 
 def test_example_training_script_two_ranks_checkpoint_and_resume(tmp_path):

@@ -165,6 +165,14 @@ long long rank1_mlp_bwd_len(long long H, long long N);
 void launch_rank1_mlp_bwd(const void* dy, const void* x, const void* w1, const void* b1, const void* W2, float* partial,
                           void* grads, long long M, long long H, long long N, int dtype, int act, hipStream_t stream);
 //   out[i] = sum over c < chunks of partial[c][i]   (fixed order)
+// Token + position embedding (bf16): out[r, :] = wte[idx[r], :] + wpe[r % T, :] and its two gradients
+// (token ids sorted by the caller, rows of absent tokens left as zeroed by the caller).
+bool embedding_supported(long long rows, long long T, long long C, long long V, long long P);
+void launch_embedding_fwd(const long long* idx, const void* wte, const void* wpe, void* out, long long rows, int T, int C, long long V,
+                          hipStream_t stream);
+void launch_embedding_bwd(const void* grad, const long long* tok_sorted, const long long* perm, void* dwte, void* dwpe, long long rows,
+                          int B, int T, int C, long long V, hipStream_t stream);
+
 void launch_reduce_partials(const float* partial, void* out, long long len, int chunks, int dtype,
                             hipStream_t stream);
 //   g = dy * act'(saved)  (+ db = colsum(g)); saved = y for ReLU, pre-activation for GELU.

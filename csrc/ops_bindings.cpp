@@ -836,9 +836,51 @@ std::tuple<Tensor, Tensor> attention_backward(Tensor d_o, Tensor qkv, Tensor o, 
   return {dqkv, dbias};
 }
 
+bool aligned16(const Tensor& t) { return reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0; }
+
+bool embedding_ok(const Tensor& idx, const Tensor& wte, const Tensor& wpe, int64_t T) {
+  return idx.is_cuda() && wte.is_cuda() && wpe.is_cuda() && idx.scalar_type() == at::kLong && wte.scalar_type() == at::kBFloat16 &&
+         wpe.scalar_type() == at::kBFloat16 && idx.is_contiguous() && wte.is_contiguous() && wpe.is_contiguous() && wte.dim() == 2 &&
+         wpe.dim() == 2 && wte.size(1) == wpe.size(1) && aligned16(wte) && aligned16(wpe) &&
+         kernels::embedding_supported(idx.numel(), T, wte.size(1), wte.size(0), wpe.size(0));
+}
+
+// idx: int64 [B, T] (or any shape whose last dimension is T) -> bf16 [idx.numel(), C]
+Tensor embedding_forward(Tensor idx, Tensor wte, Tensor wpe, int64_t T) {
+  TORCH_CHECK(embedding_ok(idx, wte, wpe, T), "embedding_forward: needs int64 ids, bf16 [V, C] / [P, C] tables with C % 8 == 0, T <= P");
+  const int64_t rows = idx.numel(), C = wte.size(1);
+  Tensor out = at::empty({rows, C}, wte.options());
+  DevGuard guard(wte);
+  kernels::launch_embedding_fwd(reinterpret_cast<const long long*>(idx.data_ptr<int64_t>()), wte.data_ptr(), wpe.data_ptr(), out.data_ptr(),
+                                rows, static_cast<int>(T), static_cast<int>(C), wte.size(0), stream_of(wte));
+  return out;
+}
+
+// grad: bf16 [rows, C]; tok_sorted / perm: the stable-sorted ids and the rows they came from.  Returns (dwte [V, C], dwpe [P, C]).
+std::tuple<Tensor, Tensor> embedding_backward(Tensor grad, Tensor tok_sorted, Tensor perm, int64_t T, int64_t V, int64_t P) {
+  check_gpu(grad, "grad");
+  check_gpu(tok_sorted, "tok_sorted");
+  check_gpu(perm, "perm");
+  TORCH_CHECK(grad.dim() == 2 && grad.scalar_type() == at::kBFloat16 && aligned16(grad), "embedding_backward: bf16 [rows, C] gradient expected");
+  const int64_t rows = grad.size(0), C = grad.size(1);
+  TORCH_CHECK(tok_sorted.scalar_type() == at::kLong && perm.scalar_type() == at::kLong && tok_sorted.numel() == rows && perm.numel() == rows,
+              "embedding_backward: sorted ids and their source rows must be int64 of one entry per gradient row");
+  TORCH_CHECK(kernels::embedding_supported(rows, T, C, V, P), "embedding_backward: unsupported shape");
+  Tensor dwte = at::zeros({V, C}, grad.options());
+  Tensor dwpe = at::zeros({P, C}, grad.options());
+  DevGuard guard(grad);
+  kernels::launch_embedding_bwd(grad.data_ptr(), reinterpret_cast<const long long*>(tok_sorted.data_ptr<int64_t>()),
+                                reinterpret_cast<const long long*>(perm.data_ptr<int64_t>()), dwte.data_ptr(), dwpe.data_ptr(), rows,
+                                static_cast<int>(rows / T), static_cast<int>(T), static_cast<int>(C), V, stream_of(grad));
+  return {dwte, dwpe};
+}
+
 }  // namespace
 
 void init_ops(py::module_& m) {
+  m.def("embedding_supported", &embedding_ok, py::arg("idx"), py::arg("wte"), py::arg("wpe"), py::arg("T"));
+  m.def("embedding_forward", &embedding_forward, py::arg("idx"), py::arg("wte"), py::arg("wpe"), py::arg("T"));
+  m.def("embedding_backward", &embedding_backward, py::arg("grad"), py::arg("tok_sorted"), py::arg("perm"), py::arg("T"), py::arg("V"), py::arg("P"));
   m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("n_head"), py::arg("softmax_scale"));
   m.def("attention_backward", &attention_backward, py::arg("do"), py::arg("qkv"), py::arg("o"), py::arg("lse"), py::arg("n_head"),
         py::arg("softmax_scale"), py::arg("want_bias_grad") = false);

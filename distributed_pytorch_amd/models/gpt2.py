@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from ..ops.attention import causal_attention_qkvpacked, projected_causal_attention
 from ..ops.cross_entropy import projection_cross_entropy, softmax_cross_entropy
+from ..ops.embedding import token_position_embedding
 from ..ops.layernorm import LayerNorm
 from ..ops.linear import library_linear_bias_act, linear_bias_act
 from ..ops.mlp import fused_mlp
@@ -186,8 +187,11 @@ class GPT2(nn.Module):
     def forward(self, idx: torch.Tensor, targets: Optional[torch.Tensor] = None):
         B, T = idx.shape
         assert T <= self.cfg.block_size
-        pos = torch.arange(T, device=idx.device)
-        x = self.wte(idx) + self.wpe(pos)
+        if self.cfg.native_ops:
+            x = token_position_embedding(idx, self.wte.weight, self.wpe.weight)  # one kernel; stock operators off the GPU
+        else:
+            pos = torch.arange(T, device=idx.device)
+            x = self.wte(idx) + self.wpe(pos)
         if self.cfg.native_ops and self.cfg.fuse_add_norm:
             pending = pending_bias = None
             for blk in self.h:

@@ -1000,3 +1000,58 @@ def test_pointwise_conv_as_gemm_matches_stock_convolution(n, cin, cout, hw):
     assert conv.weight.grad.shape == conv.weight.shape
     werr = (conv.weight.grad.float() - wr.grad).norm() / wr.grad.norm()
     assert werr < 1e-2, werr
+
+
+# ----------------------------------------------------------------------------- embedding
+@pytest.mark.parametrize("B,T,C,V,P", [(2, 16, 64, 50, 32), (3, 128, 768, 1000, 128), (8, 1024, 768, 50304, 1024), (5, 7, 8, 3, 9)])
+def test_token_position_embedding_forward_backward(B, T, C, V, P):
+    """One-kernel token + position embedding against the stock gather / add and their autograd: the forward
+    is bit-equal (fp32 sum, one rounding), the gradients equal an fp32 accumulation rounded to bf16, and two
+    runs of the backward agree bit for bit (fixed summation order, no atomics)."""
+    from distributed_pytorch_amd.ops.embedding import native_embedding_supported, token_position_embedding
+
+    torch.manual_seed(B * 100 + T)
+    wte = torch.randn(V, C, device=DEV).bfloat16().requires_grad_()
+    wpe = torch.randn(P, C, device=DEV).bfloat16().requires_grad_()
+    idx = torch.randint(0, V, (B, T), device=DEV)
+    idx[0, 0] = V - 1
+    assert native_embedding_supported(idx, wte, wpe)
+    x = token_position_embedding(idx, wte, wpe)
+    pos = torch.arange(T, device=DEV)
+    ref = torch.nn.functional.embedding(idx, wte) + torch.nn.functional.embedding(pos, wpe)
+    assert x.shape == (B, T, C) and torch.equal(x, ref)
+    g = torch.randn_like(x)
+    dwte, dwpe = torch.autograd.grad(x, (wte, wpe), g)
+    ref_wte = torch.zeros(V, C, device=DEV).index_add_(0, idx.reshape(-1), g.reshape(-1, C).float())
+    ref_wpe = torch.zeros(P, C, device=DEV)
+    ref_wpe[:T] = g.float().sum(0)
+    # fp32 accumulation in a different order, then one bf16 rounding: half a unit in the last place of the result
+    for got, want in ((dwte, ref_wte), (dwpe, ref_wpe)):
+        assert got.dtype == torch.bfloat16 and got.shape == want.shape
+        torch.testing.assert_close(got.float(), want, rtol=2 ** -7, atol=1e-3 * max(1.0, float(want.abs().max())))
+    assert torch.count_nonzero(dwpe[T:]) == 0
+    absent = torch.ones(V, dtype=torch.bool, device=DEV)
+    absent[idx.reshape(-1)] = False
+    assert torch.count_nonzero(dwte[absent]) == 0
+    again = torch.autograd.grad(token_position_embedding(idx, wte, wpe), (wte, wpe), g)
+    assert torch.equal(again[0], dwte) and torch.equal(again[1], dwpe)
+
+
+def test_token_position_embedding_fallback_and_range_check(monkeypatch):
+    from distributed_pytorch_amd.ops.embedding import native_embedding_supported, token_position_embedding
+
+    wte = torch.randn(10, 12, device=DEV).bfloat16()   # 12 columns: not a whole number of 16-byte vectors
+    wpe = torch.randn(4, 12, device=DEV).bfloat16()
+    idx = torch.randint(0, 10, (2, 4), device=DEV)
+    assert not native_embedding_supported(idx, wte, wpe)
+    assert token_position_embedding(idx, wte, wpe).shape == (2, 4, 12)
+    f32 = token_position_embedding(idx, torch.randn(10, 16, device=DEV), torch.randn(4, 16, device=DEV))  # fp32 tables: stock path
+    assert f32.dtype == torch.float32
+    wte, wpe = torch.randn(10, 16, device=DEV).bfloat16(), torch.randn(4, 16, device=DEV).bfloat16()
+    bad = idx.clone()
+    bad[1, 2] = 10
+    clamped = token_position_embedding(bad, wte, wpe)  # no fault: the id is clamped to the last row
+    assert torch.equal(clamped[1, 2], (wte[9].float() + wpe[2].float()).bfloat16())
+    monkeypatch.setenv("DIST_CHECK_TARGETS", "1")
+    with pytest.raises(IndexError):
+        token_position_embedding(bad, wte, wpe)

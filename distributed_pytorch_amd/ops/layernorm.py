@@ -34,6 +34,27 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class _KeepLayerNorm(torch.autograd.Function):
+    """(x, LN(x)) for an ``x`` that also continues as the residual stream: handing the stream back through the
+    node lets the backward kernel add the stream's gradient to the layer-norm gradient in its own pass, where
+    autograd would otherwise join the two with a separate add over the whole tensor."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, eps: float):
+        y, mean, rstd, _ = _ext.C().layernorm_forward(x2, weight, bias, eps)
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        return x2.view_as(x2), y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return ds, None, None, None
+        dres = ds.contiguous() if ds is not None else None
+        dx, dg, db, _ = _ext.C().layernorm_backward(dy.contiguous(), x2, weight, mean, rstd, dres, False)
+        return dx, dg, db, None
+
+
 class _AddLayerNorm(torch.autograd.Function):
     """(s, y) = (x + r [+ r_bias], LN(s)) in one pass; the backward folds the gradient that reaches
     ``s`` from its other consumers (the residual stream) into the layer-norm gradient in one pass
@@ -75,9 +96,15 @@ def add_layer_norm(x: torch.Tensor, r, weight: torch.Tensor, bias: torch.Tensor,
     """Returns ``(s, y)`` with ``s = x + r (+ r_bias)`` and ``y = layer_norm(s)``; ``r`` may be
     ``None`` (then ``s`` is ``x``).  One kernel on the GPU in each direction instead of add + layer
     norm; ``r_bias`` lets the layer that produced ``r`` skip its own bias add and bias-gradient pass."""
-    if r is None:
-        return x, layer_norm(x, weight, bias, eps)
     cols = x.shape[-1]
+    if r is None:
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+        if bias is None or not x.requires_grad or not _supported(x, cols, need_grad) or weight.dtype != x.dtype:
+            return x, layer_norm(x, weight, bias, eps)
+        x2 = x.reshape(-1, cols)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        s, y = _KeepLayerNorm.apply(x2, weight.contiguous(), bias.contiguous(), eps)
+        return s.reshape(x.shape), y.reshape(x.shape)
     if r_bias is not None and (not x.is_cuda or cols > 1365 or r_bias.dtype != x.dtype):
         r = r + r_bias
         r_bias = None

@@ -50,9 +50,11 @@ class _State:
     monitor_stop: Optional[threading.Event] = None
     monitor_store: Optional[Store] = None
     old_sigterm: object = None
+    comm_stream_keepalive: object = None  # torch stream installed as the communication stream, when one is
 
 
 _state: Optional[_State] = None
+_late_process: Optional[bool] = None  # did GPU work precede this process's first communicator (see init_process_group)
 
 
 def debug_sync() -> bool:
@@ -185,6 +187,32 @@ def _verify_devices(C, st: Store, state: "_State", dev: torch.device) -> None:
         raise RuntimeError(f"init_process_group: {verdict}")
 
 
+class _LibraryStdoutToStderr:
+    """While active, file descriptor 1 points at stderr.  RCCL prints a banner (HIP / ROCm version, host name,
+    library path) to the C stdout when a communicator is created; a program whose stdout is a machine-readable
+    result (the benchmark's one JSON line) must not have it there.  C streams are flushed before the descriptor
+    is restored, so nothing buffered inside the library lands on the real stdout later."""
+
+    def __enter__(self):
+        import ctypes
+
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            sys.stdout.flush()
+            self._libc.fflush(None)
+        finally:
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+        return False
+
+
 _INIT_HINT = ("check the rank->GPU map printed above; HSA_ENABLE_IPC_MODE_LEGACY=%s here (hosts whose driver only supports "
               "dmabuf IPC need it exported as 0, or peer-memory handles fail with 'hipIpcGetMemHandle: invalid argument'); "
               "NCCL_DEBUG=INFO shows the transport RCCL chose")
@@ -248,6 +276,10 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
         dev = torch.device(f"cuda:{local_device_index(rank)}")
         torch.cuda.set_device(dev)  # explicit binding; the reference leaves this to NCCL's inference
         state.device = dev
+        global _late_process
+        if _late_process is None:  # decided once, at the process's first communicator
+            _late_process = torch.cuda.memory_reserved(dev) > 0  # the process has already worked on the GPU
+        late_init = _late_process
         _verify_devices(C, st, state, dev)
         key = f"rccl/uid/{gen}"
         if rank == 0:
@@ -255,11 +287,24 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
         uid = st.get(key, timeout_s)
         # Communicator is created eagerly so that iteration 0 does not pay for it.
         try:
-            state.comm = guarded_call(lambda: C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0),
-                                      timeout_s, f"ncclCommInitRank (rank {rank} of {world_size})")
+            with _LibraryStdoutToStderr():
+                state.comm = guarded_call(lambda: C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0),
+                                          timeout_s, f"ncclCommInitRank (rank {rank} of {world_size})")
         except RuntimeError as exc:
             raise RuntimeError(f"{exc}\n  " + _INIT_HINT % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>")) from exc
         state.comm.set_debug_sync(debug_sync())
+        if late_init:
+            # Measured on MI355X (ROCm 7.0 runtime, RCCL 2.26; tools/diag_late_init.py): when the process has already
+            # run a kernel before the communicator is created, the communicator's own stream -- created right behind
+            # ncclCommInitRank, the arrangement that is right for a fresh process -- stalls for good the first time
+            # the compute stream has to wait for one of its events, while a stream taken from torch's pool at this
+            # point works.  A fresh process (the normal order: group first, model afterwards) keeps the own stream.
+            if rank == 0 and os.environ.get("DIST_QUIET_INIT", "0") != "1":
+                sys.stderr.write("[rccl] note: the process group is created after GPU work in this process; create it first "
+                                 "(before the model) -- a late communicator uses a stream of torch's pool, and re-creating "
+                                 "communicators in such a process has been seen to stall\n")
+            state.comm_stream_keepalive = torch.cuda.Stream(device=dev, priority=-1)
+            state.comm.set_comm_stream(state.comm_stream_keepalive.cuda_stream)
     else:
         state.device = torch.device("cpu") if not torch.cuda.is_available() else torch.device(f"cuda:{local_device_index(rank)}")
         if not tdist.is_initialized():

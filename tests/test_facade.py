@@ -302,6 +302,29 @@ def test_guarded_call_deadline(capsys):
     assert not fired.is_set()  # the timer is disarmed when the call returns
 
 
+def test_library_banner_is_kept_off_stdout():
+    """While a communicator is created, C-level and Python-level writes to stdout land on stderr (RCCL prints a
+    version banner there), and stdout works again afterwards: the benchmark's stdout stays one JSON line."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    code = (
+        "import ctypes\n"
+        "from distributed_pytorch_amd.parallel.process_group import _LibraryStdoutToStderr\n"
+        "libc = ctypes.CDLL(None)\n"
+        "print('before')\n"
+        "with _LibraryStdoutToStderr():\n"
+        "    libc.printf(b'banner from C\\n')\n"
+        "    print('inside python')\n"
+        "print('after')\n"
+    )
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent), timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert p.stdout == "before\nafter\n"
+    assert "banner from C" in p.stderr and "inside python" in p.stderr
+
+
 def test_launcher_leaves_ipc_mode_alone(monkeypatch):
     """Runtime variables that change how peer mappings are opened reach the workers as exported,
     never invented by the launcher."""

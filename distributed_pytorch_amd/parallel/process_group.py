@@ -293,13 +293,18 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
         except RuntimeError as exc:
             raise RuntimeError(f"{exc}\n  " + _INIT_HINT % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>")) from exc
         state.comm.set_debug_sync(debug_sync())
+        # DIST_COMM_STREAM=own | pool overrides the choice below (a switch for the day a new runtime, or a world size
+        # this was not measured at, behaves differently).
+        choice = os.environ.get("DIST_COMM_STREAM", "").lower()
+        if choice in ("own", "pool"):
+            late_init = choice == "pool"
         if late_init:
             # Measured on MI355X (ROCm 7.0 runtime, RCCL 2.26; tools/diag_late_init.py): when the process has already
             # run a kernel before the communicator is created, the communicator's own stream -- created right behind
             # ncclCommInitRank, the arrangement that is right for a fresh process -- stalls for good the first time
             # the compute stream has to wait for one of its events, while a stream taken from torch's pool at this
             # point works.  A fresh process (the normal order: group first, model afterwards) keeps the own stream.
-            if rank == 0 and os.environ.get("DIST_QUIET_INIT", "0") != "1":
+            if rank == 0 and choice != "pool" and os.environ.get("DIST_QUIET_INIT", "0") != "1":
                 sys.stderr.write("[rccl] note: the process group is created after GPU work in this process; create it first "
                                  "(before the model) -- a late communicator uses a stream of torch's pool, and re-creating "
                                  "communicators in such a process has been seen to stall\n")

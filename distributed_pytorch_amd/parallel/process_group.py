@@ -20,6 +20,7 @@ import signal
 import socket
 import sys
 import threading
+import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -339,6 +340,9 @@ def _start_hang_detection(state: "_State") -> None:
         def on_hang(v):
             sys.stderr.write(f"[hang monitor] {v.message()}; terminating the job\n")
             sys.stderr.flush()
+            # the abort key is posted; this rank hosts the store, so it stays up long enough for the other ranks'
+            # heartbeat threads (one poll per interval) to read the key, abort their communicators and leave too
+            time.sleep(2.5 * hb.heartbeat_interval_s())
             abort()
             os._exit(hb.EXIT_CODE_ABORTED)
 

@@ -269,6 +269,9 @@ def run_rank(rank: int, world_size: int, argv):
         "final_loss": round(final_loss, 5),
         "first_loss": round(float(first_loss.detach().float().item()), 5) if first_loss is not None else None,
     }
+    if on_rccl:
+        info_cs = pg.comm_stream_info() or {}
+        result["config"]["comm_stream"] = {k: info_cs.get(k) for k in ("priority", "independent", "candidates_tried")}
     if use_gpu:
         result["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
         result["peak_reserved_gb"] = round(torch.cuda.max_memory_reserved(device) / 2**30, 2)
@@ -277,14 +280,24 @@ def run_rank(rank: int, world_size: int, argv):
     if world_size > 1 or rccl_extras:
         # Everything below is collective and runs after the timed region: a rank that fails inside it leaves the
         # others waiting.  Every rank therefore arms a deadline; when it passes, rank 0 prints the line it already
-        # has and all ranks leave without tearing the communicator down.
+        # has, every rank says on stderr which extra it was in, the communicator is aborted and the process ends
+        # with the hang monitor's status (86): a collective that hangs after the timed steps is a hang, and must
+        # be recorded as one by whoever launched the job.
         import threading
 
+        from distributed_pytorch_amd.parallel import heartbeat as hb
+
         def _give_up():
+            sys.stderr.write(f"[bench rank {rank}] post-run extras did not finish within {int(extras_deadline)} s; "
+                             f"stuck in: {extras_phase[0]}\n")
+            sys.stderr.flush()
             if dist.is_primary():
-                result["extras"] = "abandoned after %d s" % int(extras_deadline)
+                result["extras"] = "abandoned after %d s in %s" % (int(extras_deadline), extras_phase[0])
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            pg.abort()
+            os._exit(hb.EXIT_CODE_ABORTED)
+
+        extras_phase = ["start"]
 
         extras_deadline = float(os.environ.get("BENCH_EXTRAS_DEADLINE_S", "120"))
         bail = threading.Timer(extras_deadline, _give_up)
@@ -294,6 +307,8 @@ def run_rank(rank: int, world_size: int, argv):
         # Every rank's parameters must still be bit-identical (same averaged gradients, same update), which is what
         # a stream-ordering or bucket-layout bug in the data-parallel path would break.
         try:
+            if bail is not None:
+                extras_phase[0] = "check_replicas_in_sync"
             result["replicas_in_sync"] = bool(model.check_replicas_in_sync())
         except Exception as exc:  # noqa: BLE001 - diagnostic extra only
             result["replicas_in_sync"] = f"failed: {type(exc).__name__}: {exc}"
@@ -304,10 +319,12 @@ def run_rank(rank: int, world_size: int, argv):
         #  * all-reduce bus bandwidth over bucket-sized messages, on the reducer's own path (communication
         #    stream + event fences), so the bucket size can be read off the curve.
         try:
+            extras_phase[0] = "overlap report (3 extra steps)"
             result.update(_overlap_report(pg, step, device, model))
         except Exception as exc:  # noqa: BLE001 - diagnostic extra only
             result["exposed_comm_ms"] = f"failed: {type(exc).__name__}: {exc}"
         try:
+            extras_phase[0] = "all-reduce bus-bandwidth sweep"
             result["allreduce_busbw_gbps"] = _allreduce_busbw(pg, dist, device, max(world_size, 1))
         except Exception as exc:  # noqa: BLE001 - diagnostic extra only
             result["allreduce_busbw_gbps"] = f"failed: {type(exc).__name__}: {exc}"

@@ -97,7 +97,7 @@ def _torch_paths():
 
 def _gpu_sources():
     kernels = sorted((CSRC / "kernels").glob("*.hip"))
-    torch_cpp = [p for p in [CSRC / "bindings.cpp", CSRC / "comm" / "rccl_comm.cpp", CSRC / "reducer" / "reducer.cpp", CSRC / "ops_bindings.cpp"] if p.exists()]
+    torch_cpp = [p for p in [CSRC / "bindings.cpp", CSRC / "comm" / "rccl_comm.cpp", CSRC / "comm" / "comm_stream.cpp", CSRC / "reducer" / "reducer.cpp", CSRC / "ops_bindings.cpp"] if p.exists()]
     plain_cpp = [CSRC / "store" / "tcp_store.cpp", CSRC / "reducer" / "bucket_plan.cpp"]
     return kernels, torch_cpp, plain_cpp
 

@@ -19,12 +19,12 @@ PYBIND11_MODULE(_C, m) {
       .def_static("unique_id", []() { return py::bytes(RcclComm::unique_id()); })
       .def_static("device_bus_id", &RcclComm::device_bus_id, py::arg("device"))
       .def_static("version", &RcclComm::version)
-      .def(py::init([](py::bytes uid, int rank, int world, int device) {
+      .def(py::init([](py::bytes uid, int rank, int world, int device, bool high_priority_stream) {
              std::string s = uid;
              py::gil_scoped_release nogil;  // blocks until every rank has joined
-             return std::make_shared<RcclComm>(s, rank, world, device);
+             return std::make_shared<RcclComm>(s, rank, world, device, high_priority_stream);
            }),
-           py::arg("uid"), py::arg("rank"), py::arg("world"), py::arg("device"))
+           py::arg("uid"), py::arg("rank"), py::arg("world"), py::arg("device"), py::arg("high_priority_stream") = false)
       .def_property_readonly("rank", &RcclComm::rank)
       .def_property_readonly("world", &RcclComm::world)
       .def_property_readonly("device", &RcclComm::device)
@@ -42,6 +42,20 @@ PYBIND11_MODULE(_C, m) {
       .def("synchronize_comm_stream", &RcclComm::synchronize_comm_stream, py::call_guard<py::gil_scoped_release>())
       .def("comm_stream_handle", [](RcclComm& c) { return reinterpret_cast<uintptr_t>(c.comm_stream()); })
       .def("set_comm_stream", &RcclComm::set_comm_stream, py::arg("handle"))
+      .def("comm_stream_info",
+           [](RcclComm& c) {
+             c.comm_stream();
+             const CommStreamChoice& ch = c.comm_stream_choice();
+             py::dict d;
+             d["priority"] = ch.high_priority ? "high" : "normal";
+             d["independent"] = ch.independent;
+             d["candidates_tried"] = ch.candidates_tried;
+             d["reused"] = ch.reused;
+             d["probe_ms"] = ch.probe_ms;
+             d["text"] = ch.describe();
+             return d;
+           })
+      .def("aborted", &RcclComm::aborted)
       .def("group_start", &RcclComm::group_start)
       .def("group_end", &RcclComm::group_end)
       .def("num_async_ops", &RcclComm::num_async_ops)
@@ -52,6 +66,16 @@ PYBIND11_MODULE(_C, m) {
       .def("comm_stream_idle", &RcclComm::comm_stream_idle)
       .def("set_timing", &RcclComm::set_timing, py::arg("on"))
       .def("read_timing", &RcclComm::read_timing, py::call_guard<py::gil_scoped_release>());
+
+  m.def(
+      "probe_stream_independence",
+      [](int device, uintptr_t candidate, uintptr_t compute, double hold_ms) {
+        py::gil_scoped_release nogil;
+        return probe_stream_independence(device, reinterpret_cast<hipStream_t>(candidate), reinterpret_cast<hipStream_t>(compute),
+                                         hold_ms);
+      },
+      py::arg("device"), py::arg("candidate"), py::arg("compute"), py::arg("hold_ms") = 3.0,
+      "Milliseconds a one-lane kernel on `compute` needed while a hold_ms spin ran on `candidate`");
 
   py::class_<Transport, std::shared_ptr<Transport>>(m, "Transport")
       .def("native_average", &Transport::native_average)

@@ -2,6 +2,7 @@
 
 #include <c10/hip/HIPStream.h>
 
+#include <chrono>
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
@@ -85,20 +86,15 @@ std::string RcclComm::version() {
   return os.str();
 }
 
-RcclComm::RcclComm(const std::string& uid, int rank, int world, int device)
-    : rank_(rank), world_(world), device_(device) {
+RcclComm::RcclComm(const std::string& uid, int rank, int world, int device, bool high_priority_stream)
+    : rank_(rank), world_(world), device_(device), want_high_(high_priority_stream) {
   if (uid.size() != sizeof(ncclUniqueId)) throw std::runtime_error("RcclComm: bad unique id size");
   ncclUniqueId id;
   std::memcpy(&id, uid.data(), sizeof(id));
   DPA_HIP_CHECK(hipSetDevice(device_));
   DPA_NCCL_CHECK(ncclCommInitRank(&comm_, world_, id, rank_));
-  // The communication stream is created only now, AFTER the communicator exists, and it is a stream of
-  // our own rather than one from torch's pool (whose streams all come into being at the first use of
-  // the pool, possibly before this communicator).  Measured on MI355X (ROCm 7.0 runtime, RCCL 2.26): a
-  // stream that already existed when ncclCommInitRank ran never returned from its first wait on an
-  // event the compute stream had not reached yet (one-rank group, 4 MiB bucket behind eight queued
-  // matmuls; tools/diag_comm_sizes.py and tools/diag_ddp_step.py reproduce it); with a stream created
-  // afterwards every probe passes.  Waits on already-completed events hid the problem in small tests.
+  // The communication stream is the process's one long-lived stream for this device (comm_stream.h): chosen
+  // by a bounded probe at the first communicator, reused by every later one.
   ensure_comm_stream();
   barrier_scratch_ = at::zeros({1}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, device_));
 }
@@ -114,11 +110,14 @@ void RcclComm::destroy() {
   if (destroyed_) return;
   destroyed_ = true;
   DeviceGuard g(device_);
-  if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
-  if (comm_) {
-    (void)ncclCommFinalize(comm_);
-    (void)ncclCommDestroy(comm_);
-    comm_ = nullptr;
+  if (comm_stream_ && !aborted_.load()) (void)hipStreamSynchronize(comm_stream_);
+  {
+    std::lock_guard<std::timed_mutex> lk(comm_mu_);
+    if (comm_) {
+      (void)ncclCommFinalize(comm_);
+      (void)ncclCommDestroy(comm_);
+      comm_ = nullptr;
+    }
   }
   for (hipEvent_t e : slot_events_)
     if (e) (void)hipEventDestroy(e);
@@ -131,22 +130,32 @@ void RcclComm::destroy() {
   timing_pool_.clear();
   op_spans_.clear();
   wait_spans_.clear();
-  if (comm_stream_ && owns_comm_stream_) (void)hipStreamDestroy(comm_stream_);
-  comm_stream_ = nullptr;
+  comm_stream_ = nullptr;  // the stream itself belongs to the process (comm_stream.h) and stays
   barrier_scratch_ = at::Tensor();
 }
 
 void RcclComm::abort() {
-  if (comm_) {
-    (void)ncclCommAbort(comm_);
-    comm_ = nullptr;
-  }
+  aborted_.store(true);  // from here on no enqueue path touches comm_ any more
+  std::unique_lock<std::timed_mutex> lk(comm_mu_, std::chrono::milliseconds(2000));
+  // Not acquired: the training thread is blocked inside a library call that holds the mutex -- the very
+  // situation abort is for; ncclCommAbort is what releases it.
+  ncclComm_t c = comm_;
+  comm_ = nullptr;
+  if (c) (void)ncclCommAbort(c);
 }
 
 void RcclComm::check_tensor(const at::Tensor& t) const {
+  if (aborted_.load()) throw std::runtime_error("RcclComm: communicator was aborted");
   if (destroyed_ || !comm_) throw std::runtime_error("RcclComm: communicator already destroyed");
   if (!t.is_cuda()) throw std::runtime_error("RcclComm: tensor must live on the GPU");
-  if (t.get_device() != device_) throw std::runtime_error("RcclComm: tensor is on a different device than the communicator");
+  if (t.get_device() != device_) {
+    std::ostringstream os;
+    os << "RcclComm: tensor is on cuda:" << t.get_device() << " but this rank's communicator is bound to cuda:" << device_
+       << ".  With the launcher's default GPU binding (DIST_GPU_BINDING=rotate) every rank sees ITS GPU as cuda:0 -- use "
+          "distributed.get_device() instead of f\"cuda:{rank}\", or launch with DIST_GPU_BINDING=index to keep device "
+          "index == rank as in the reference";
+    throw std::runtime_error(os.str());
+  }
   if (!t.is_contiguous()) throw std::runtime_error("RcclComm: tensor must be contiguous");
 }
 
@@ -154,6 +163,8 @@ void RcclComm::all_reduce(at::Tensor t, int op) {
   check_tensor(t);
   if (t.numel() == 0) return;
   DeviceGuard g(device_);
+  std::lock_guard<std::timed_mutex> lk(comm_mu_);
+  if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
   DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                static_cast<ncclRedOp_t>(op), comm_, current_stream(device_)));
 }
@@ -162,6 +173,8 @@ void RcclComm::reduce(at::Tensor t, int root, int op) {
   check_tensor(t);
   if (t.numel() == 0) return;
   DeviceGuard g(device_);
+  std::lock_guard<std::timed_mutex> lk(comm_mu_);
+  if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
   DPA_NCCL_CHECK(ncclReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                             static_cast<ncclRedOp_t>(op), root, comm_, current_stream(device_)));
 }
@@ -170,6 +183,8 @@ void RcclComm::broadcast(at::Tensor t, int root) {
   check_tensor(t);
   if (t.numel() == 0) return;
   DeviceGuard g(device_);
+  std::lock_guard<std::timed_mutex> lk(comm_mu_);
+  if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
   DPA_NCCL_CHECK(ncclBroadcast(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                root, comm_, current_stream(device_)));
 }
@@ -185,6 +200,8 @@ void RcclComm::gather(at::Tensor in, c10::optional<at::Tensor> out, int root) {
   }
   if (in.numel() == 0) return;
   DeviceGuard g(device_);
+  std::lock_guard<std::timed_mutex> lk(comm_mu_);
+  if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
   DPA_NCCL_CHECK(ncclGather(in.data_ptr(), recv, static_cast<size_t>(in.numel()), to_nccl_dtype(in.scalar_type()), root,
                             comm_, current_stream(device_)));
 }
@@ -195,6 +212,8 @@ void RcclComm::all_gather(at::Tensor in, at::Tensor out) {
   if (out.numel() != in.numel() * world_) throw std::runtime_error("RcclComm::all_gather: output must hold world * input elements");
   if (in.numel() == 0) return;
   DeviceGuard g(device_);
+  std::lock_guard<std::timed_mutex> lk(comm_mu_);
+  if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
   DPA_NCCL_CHECK(ncclAllGather(in.data_ptr(), out.data_ptr(), static_cast<size_t>(in.numel()), to_nccl_dtype(in.scalar_type()),
                                comm_, current_stream(device_)));
 }
@@ -205,6 +224,8 @@ void RcclComm::reduce_scatter(at::Tensor in, at::Tensor out, int op) {
   if (in.numel() != out.numel() * world_) throw std::runtime_error("RcclComm::reduce_scatter: input must hold world * output elements");
   if (out.numel() == 0) return;
   DeviceGuard g(device_);
+  std::lock_guard<std::timed_mutex> lk(comm_mu_);
+  if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
   DPA_NCCL_CHECK(ncclReduceScatter(in.data_ptr(), out.data_ptr(), static_cast<size_t>(out.numel()),
                                    to_nccl_dtype(in.scalar_type()), static_cast<ncclRedOp_t>(op), comm_,
                                    current_stream(device_)));
@@ -214,32 +235,29 @@ void RcclComm::barrier() {
   if (destroyed_ || !comm_) throw std::runtime_error("RcclComm: communicator already destroyed");
   DeviceGuard g(device_);
   hipStream_t s = current_stream(device_);
-  DPA_NCCL_CHECK(ncclAllReduce(barrier_scratch_.data_ptr(), barrier_scratch_.data_ptr(), 1, ncclFloat32, ncclSum, comm_, s));
-  DPA_HIP_CHECK(hipStreamSynchronize(s));
+  {
+    std::lock_guard<std::timed_mutex> lk(comm_mu_);
+    if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
+    DPA_NCCL_CHECK(ncclAllReduce(barrier_scratch_.data_ptr(), barrier_scratch_.data_ptr(), 1, ncclFloat32, ncclSum, comm_, s));
+  }
+  DPA_HIP_CHECK(hipStreamSynchronize(s));  // outside the mutex: abort() must be able to get in while this blocks
 }
 
 // Prepares slot `slot` for a new operation: events exist, and a previous operation on the same
 // slot that nobody waited for has finished.  An event is never re-recorded while a stream may
 // still be waiting on its previous record: every slot owns its own fence and completion event.
 void RcclComm::ensure_comm_stream() {
-  // High-priority stream (non-blocking with respect to the default stream), so RCCL kernels are
-  // scheduled ahead of queued backward kernels.  Created by the constructor right after the
-  // communicator unless the caller installs one with set_comm_stream().
   if (!comm_stream_) {
-    int least = 0, greatest = 0;
-    DPA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    DPA_HIP_CHECK(hipStreamCreateWithPriority(&comm_stream_, hipStreamNonBlocking, greatest));
-    owns_comm_stream_ = true;
+    choice_ = acquire_comm_stream(device_, current_stream(device_), want_high_);
+    comm_stream_ = choice_.stream;
   }
 }
 
 void RcclComm::set_comm_stream(uintptr_t handle) {
-  if (comm_stream_ && owns_comm_stream_) {
-    (void)hipStreamSynchronize(comm_stream_);
-    (void)hipStreamDestroy(comm_stream_);
-  }
+  if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
   comm_stream_ = reinterpret_cast<hipStream_t>(handle);
-  owns_comm_stream_ = false;
+  choice_ = CommStreamChoice();
+  choice_.stream = comm_stream_;
 }
 
 void RcclComm::begin_slot(int slot) {
@@ -296,9 +314,12 @@ void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
     t0 = timing_event();
     DPA_HIP_CHECK(hipEventRecord(t0, comm_stream_));
   }
-  if (t.numel() > 0)
+  if (t.numel() > 0) {
+    std::lock_guard<std::timed_mutex> lk(comm_mu_);
+    if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
     DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                  static_cast<ncclRedOp_t>(op), comm_, comm_stream_));
+  }
   finish_async(slot, done, t0);
 }
 
@@ -314,9 +335,12 @@ void RcclComm::broadcast_async(at::Tensor t, int root, int slot) {
     t0 = timing_event();
     DPA_HIP_CHECK(hipEventRecord(t0, comm_stream_));
   }
-  if (t.numel() > 0)
+  if (t.numel() > 0) {
+    std::lock_guard<std::timed_mutex> lk(comm_mu_);
+    if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
     DPA_NCCL_CHECK(ncclBroadcast(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
                                  root, comm_, comm_stream_));
+  }
   finish_async(slot, done, t0);
 }
 

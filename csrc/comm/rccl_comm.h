@@ -3,9 +3,10 @@
 // This is the GPU data plane behind every collective of the `distributed` facade -- the
 // role ProcessGroupNCCL plays for the reference (reference distributed.py:62-66, 119-177):
 //   * the ncclUniqueId travels through our TCP store, the communicator is created eagerly;
-//   * a dedicated high-priority HIP stream carries the gradient-bucket all-reduces so they
-//     overlap the backward kernels running on torch's current stream; ordering between the
-//     two streams is expressed with hipEvents only (no host synchronisation);
+//   * a dedicated HIP stream (one per process and device, see comm_stream.h for how it is chosen)
+//     carries the gradient-bucket all-reduces so they overlap the backward kernels running on
+//     torch's current stream; ordering between the two streams is expressed with hipEvents only
+//     (no host synchronisation);
 //   * metric-sized collectives (reduce / gather / barrier) are issued on the current stream,
 //     where a dependency on the preceding kernels already exists, so they cost no fences;
 //   * gather uses RCCL's native ncclGather instead of grouped send/recv.
@@ -16,9 +17,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
+
+#include "comm/comm_stream.h"
 
 namespace dpa {
 
@@ -30,7 +35,9 @@ class RcclComm {
   static std::string device_bus_id(int device);
   static std::string version();  // "2.26.6"-style RCCL version string
 
-  RcclComm(const std::string& uid, int rank, int world, int device);
+  // high_priority_stream: ask for a high-priority communication stream (only used when the probe of
+  // comm_stream.h finds one that is independent of the compute stream; normal priority otherwise).
+  RcclComm(const std::string& uid, int rank, int world, int device, bool high_priority_stream = false);
   ~RcclComm();
   RcclComm(const RcclComm&) = delete;
   RcclComm& operator=(const RcclComm&) = delete;
@@ -62,12 +69,19 @@ class RcclComm {
   }
   // Use an existing stream (e.g. a torch.cuda.Stream created by the caller) for the async ops.
   void set_comm_stream(uintptr_t handle);
+  // How the communication stream was chosen (priority, probe results).
+  const CommStreamChoice& comm_stream_choice() const { return choice_; }
 
   void group_start();
   void group_end();
 
   void destroy();  // ncclCommFinalize + ncclCommDestroy; idempotent
-  void abort();    // ncclCommAbort: unblocks kernels of a collective a peer never joined (teardown on hang)
+  // ncclCommAbort: unblocks kernels of a collective a peer never joined (teardown on hang).  May be called
+  // from another thread (heartbeat, signal watcher) while the training thread is enqueueing: enqueues hold
+  // `comm_mu_` around the library call and give up once `aborted_` is set; abort() takes the same mutex, but
+  // only waits a bounded time for it (a training thread blocked INSIDE the library is the case abort exists for).
+  void abort();
+  bool aborted() const { return aborted_.load(); }
 
   int64_t num_async_ops() const { return n_async_; }
 
@@ -93,9 +107,12 @@ class RcclComm {
   void check_tensor(const at::Tensor& t) const;
 
   ncclComm_t comm_ = nullptr;
+  std::timed_mutex comm_mu_;          // guards comm_ against abort() from another thread
+  std::atomic<bool> aborted_{false};
   int rank_, world_, device_;
+  bool want_high_ = false;
   hipStream_t comm_stream_ = nullptr;
-  bool owns_comm_stream_ = false;
+  CommStreamChoice choice_;
   std::vector<hipEvent_t> slot_events_;   // completion of the operation on the comm stream
   std::vector<hipEvent_t> fence_events_;  // "inputs are ready" on the stream that produced them
   std::vector<char> slot_pending_;

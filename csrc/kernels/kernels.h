@@ -30,6 +30,16 @@ void launch_multi_copy_scale(const CopyTable& t, int src_dtype, int dst_dtype, f
                              hipStream_t stream);
 void launch_scale_inplace(void* p, long long n, int dtype, float scale, hipStream_t stream);
 
+// ------------------------------------------------------------------ communication-stream helpers
+// A bounded spin of `milliseconds` (one wave, sleeps between clock reads) and a one-lane increment: the pair
+// answers "can stream B make progress while stream A has a kernel running".
+void launch_spin(float* scratch, double milliseconds, hipStream_t stream);
+void launch_touch(float* scratch, hipStream_t stream);
+// One-GPU stand-in for a multi-rank collective: `workgroups` workgroups stay resident for `milliseconds` and
+// move `bytes` of `buf` `passes` times through HBM (values unchanged), paced over that time.
+void launch_emulated_collective(void* buf, long long bytes, int workgroups, int passes, double milliseconds,
+                                hipStream_t stream);
+
 // ------------------------------------------------------------------ fused AdamW
 // Hyper-parameters live in device memory so a captured graph replays with the current
 // learning rate and step: [lr, beta1, beta2, eps, weight_decay, step(as int bits),

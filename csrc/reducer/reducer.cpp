@@ -71,10 +71,11 @@ class C10dTransport final : public Transport {
   bool native_average() const override { return false; }
   // GPU tensors on a host-side group (gloo) are staged through host memory HERE, with plain synchronous copies on
   // the current stream, and the group only ever sees CPU tensors.  Handing it the GPU tensor makes the group stage
-  // it itself on streams of torch's pool, with event waits between those streams and the compute stream in both
-  // directions; on this runtime such a wait on an event the other stream has not reached yet has been seen never to
-  // return (the stall described at RcclComm's own stream): with a real model's backlog on the compute stream always,
-  // with a short backward and two ranks sharing the GPU about every other run.  This path is a plumbing
+  // it itself on HIGH-PRIORITY streams of torch's pool, with event waits between those streams and the compute
+  // stream in both directions.  A high-priority hardware queue that shares a command-processor pipe with the
+  // compute stream's queue keeps that pipe while it waits, so the compute queue can never signal the event it
+  // waits for (comm/comm_stream.h); which queue lands on which pipe depends on how many queues the process made
+  // before, hence "always with one model, every other run with another".  This path is a plumbing
   // configuration (several ranks sharing one GPU in tests), not a fast one, so nothing is overlapped.
   static void reduce_through_host(c10d::ProcessGroup& pg, at::Tensor& t) {
     at::Tensor h = t.to(at::kCPU);  // device-to-host copy; returns when the data is there

@@ -114,8 +114,7 @@ class HangVerdict:
         if self.kind == "lag":
             return (f"no progress for {self.waited_s:.0f} s: {who} never entered collective #{ahead} "
                     f"that the other ranks are waiting in")
-        return (f"no rank has entered a collective for {self.waited_s:.0f} s; all at #{ahead}: {who}"
-                " (if every rank sits in its first collectives on the communication stream, DIST_COMM_STREAM=pool selects the other stream arrangement)")
+        return (f"no rank has entered a collective for {self.waited_s:.0f} s; all at #{ahead}: {who}")
 
 
 class HangMonitor:

@@ -51,11 +51,10 @@ class _State:
     monitor_stop: Optional[threading.Event] = None
     monitor_store: Optional[Store] = None
     old_sigterm: object = None
-    comm_stream_keepalive: object = None  # torch stream installed as the communication stream, when one is
+    comm_stream_info: Optional[dict] = None  # how the communication stream was chosen (RcclComm.comm_stream_info)
 
 
 _state: Optional[_State] = None
-_late_process: Optional[bool] = None  # did GPU work precede this process's first communicator (see init_process_group)
 
 
 def debug_sync() -> bool:
@@ -246,6 +245,16 @@ def guarded_call(fn, timeout_s: float, what: str, on_timeout=None):
         timer.cancel()
 
 
+def comm_stream_wants_high_priority() -> bool:
+    """``DIST_COMM_STREAM=normal`` (default) | ``high``.  ``high`` asks for a high-priority communication stream; it is
+    only used when the start-up probe finds one whose hardware queue does not share a command-processor pipe with
+    the compute stream's (a high-priority queue on that pipe starves the compute queue, see comm_stream.h)."""
+    v = os.environ.get("DIST_COMM_STREAM", "normal").lower()
+    if v not in ("normal", "high"):
+        raise ValueError(f"DIST_COMM_STREAM={v!r}: expected 'normal' or 'high'")
+    return v == "high"
+
+
 # ------------------------------------------------------------------------------ lifecycle
 def init_process_group(rank: int, world_size: int, backend: Optional[str] = None, *, timeout_s: Optional[float] = None, store: Optional[Store] = None) -> None:
     global _state
@@ -277,10 +286,6 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
         dev = torch.device(f"cuda:{local_device_index(rank)}")
         torch.cuda.set_device(dev)  # explicit binding; the reference leaves this to NCCL's inference
         state.device = dev
-        global _late_process
-        if _late_process is None:  # decided once, at the process's first communicator
-            _late_process = torch.cuda.memory_reserved(dev) > 0  # the process has already worked on the GPU
-        late_init = _late_process
         _verify_devices(C, st, state, dev)
         key = f"rccl/uid/{gen}"
         if rank == 0:
@@ -289,28 +294,20 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
         # Communicator is created eagerly so that iteration 0 does not pay for it.
         try:
             with _LibraryStdoutToStderr():
-                state.comm = guarded_call(lambda: C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0),
+                state.comm = guarded_call(lambda: C.RcclComm(uid, rank, world_size, dev.index if dev.index is not None else 0,
+                                                             comm_stream_wants_high_priority()),
                                           timeout_s, f"ncclCommInitRank (rank {rank} of {world_size})")
         except RuntimeError as exc:
             raise RuntimeError(f"{exc}\n  " + _INIT_HINT % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>")) from exc
         state.comm.set_debug_sync(debug_sync())
-        # DIST_COMM_STREAM=own | pool overrides the choice below (a switch for the day a new runtime, or a world size
-        # this was not measured at, behaves differently).
-        choice = os.environ.get("DIST_COMM_STREAM", "").lower()
-        if choice in ("own", "pool"):
-            late_init = choice == "pool"
-        if late_init:
-            # Measured on MI355X (ROCm 7.0 runtime, RCCL 2.26; tools/diag_late_init.py): when the process has already
-            # run a kernel before the communicator is created, the communicator's own stream -- created right behind
-            # ncclCommInitRank, the arrangement that is right for a fresh process -- stalls for good the first time
-            # the compute stream has to wait for one of its events, while a stream taken from torch's pool at this
-            # point works.  A fresh process (the normal order: group first, model afterwards) keeps the own stream.
-            if rank == 0 and choice != "pool" and os.environ.get("DIST_QUIET_INIT", "0") != "1":
-                sys.stderr.write("[rccl] note: the process group is created after GPU work in this process; create it first "
-                                 "(before the model) -- a late communicator uses a stream of torch's pool, and re-creating "
-                                 "communicators in such a process has been seen to stall\n")
-            state.comm_stream_keepalive = torch.cuda.Stream(device=dev, priority=-1)
-            state.comm.set_comm_stream(state.comm_stream_keepalive.cuda_stream)
+        # The communication stream is chosen here, once per process and device (csrc/comm/comm_stream.h): a stream of
+        # normal priority -- or, with DIST_COMM_STREAM=high, of high priority -- that a bounded probe has seen run
+        # concurrently with the compute stream.  Every later communicator of the process reuses it.
+        info = state.comm.comm_stream_info()
+        state.comm_stream_info = info
+        if not info["independent"] and rank == 0 and os.environ.get("DIST_QUIET_INIT", "0") != "1":
+            sys.stderr.write(f"[rccl] note: no stream independent of the compute stream was found ({info['text']}); gradient "
+                             "all-reduces will not overlap the backward pass (is GPU_MAX_HW_QUEUES very small?)\n")
     else:
         state.device = torch.device("cpu") if not torch.cuda.is_available() else torch.device(f"cuda:{local_device_index(rank)}")
         if not tdist.is_initialized():
@@ -363,6 +360,12 @@ def _start_hang_detection(state: "_State") -> None:
             state.old_sigterm = signal.signal(signal.SIGTERM, _on_term)
         except ValueError:
             state.old_sigterm = None
+
+
+def comm_stream_info() -> Optional[dict]:
+    """How this process's communication stream was chosen (priority, probe result), or None without RCCL."""
+    st = _state
+    return None if st is None else st.comm_stream_info
 
 
 def abort() -> None:

@@ -29,8 +29,9 @@ class GraphedStep:
         self.replays = 0
         # Warm-up on a side stream: lazy state (optimizer moments, workspaces) is allocated here,
         # outside the capture.
-        # (the current stream is drained first: on this runtime a pool stream that has to wait for an event the
-        # busy compute stream has not reached yet may never be released -- see the note at RcclComm's stream)
+        # (the current stream is drained first, so the side stream's wait below is on a finished event: a stream
+        # whose hardware queue shares a command-processor pipe with the compute stream's at another priority
+        # must never wait for an unfinished event of it -- csrc/comm/comm_stream.h)
         torch.cuda.current_stream().synchronize()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())

@@ -512,3 +512,89 @@ def test_bench_bus_bandwidth_probe_runs_on_the_reducer_path(rccl_group):
     out = bench._allreduce_busbw(rccl_group, dist, torch.device("cuda", 0), 1, sizes_mb=(1, 4), iters=3)
     assert out == {"1MiB": 0.0, "4MiB": 0.0}
     assert rccl_group.get_comm().num_async_ops() == n0 + 2 * (2 + 3)
+
+
+def _reducer_stream_sequence(comm, reps=2):
+    """The reducer's stream traffic on four 4 MiB buckets behind a backlog of matmuls: fill on the compute stream,
+    all-reduce on the communication stream (which therefore waits for an event the compute stream has not
+    reached yet), compute stream waits for the completion events, host consumes."""
+    x = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    bufs = [torch.zeros(1 << 20, device=DEV) for _ in range(4)]
+    for rep in range(reps):
+        for i, buf in enumerate(bufs):
+            for _ in range(4):
+                x = (x @ x).clamp_(-1, 1)           # keeps the compute stream busy ahead of the fence
+            buf.add_(1.0)
+            comm.all_reduce_async(buf, 4, i)
+        comm.wait_all_slots()
+        assert [b.sum().item() for b in bufs] == [float(rep + 1) * (1 << 20)] * 4
+
+
+def test_eight_groups_after_gpu_work_share_one_probed_stream():
+    """Communicators created one after another in a process that has long been using the GPU (this test file runs
+    behind the kernel tests): every one gets the SAME long-lived communication stream, chosen once by the bounded
+    independence probe, and the reducer's stream sequence runs on each of them."""
+    from distributed_pytorch_amd.parallel import process_group as pg
+    from distributed_pytorch_amd.parallel.store import Store
+
+    (torch.randn(1024, 1024, device=DEV) @ torch.randn(1024, 1024, device=DEV)).sum().item()   # GPU work first
+    handles = []
+    for k in range(8):
+        store = Store("127.0.0.1", 0, is_host=True, bind_addr="127.0.0.1")
+        pg.init_process_group(0, 1, "rccl", store=store)
+        try:
+            comm = pg.get_comm()
+            info = pg.comm_stream_info()
+            assert info["independent"], info            # the probe found a stream that overlaps the compute stream
+            assert info["priority"] == os.environ.get("DIST_COMM_STREAM", "normal")
+            handles.append(comm.comm_stream_handle())
+            _reducer_stream_sequence(comm)
+        finally:
+            pg.destroy_process_group()
+    assert len(set(handles)) == 1, handles
+
+
+def test_stream_independence_probe_tells_shared_from_separate_queues():
+    """The probe behind the stream choice: a kernel on the compute stream is held up by a spin kernel on the SAME
+    stream, and is not by one on the chosen communication stream."""
+    from distributed_pytorch_amd import _ext
+    from distributed_pytorch_amd.parallel import process_group as pg
+    from distributed_pytorch_amd.parallel.store import Store
+
+    C = _ext.C()
+    cur = torch.cuda.current_stream().cuda_stream
+    same = C.probe_stream_independence(0, cur, cur, 3.0)
+    assert same > 2.0, same                                # behind the 3 ms spin on its own stream
+    store = Store("127.0.0.1", 0, is_host=True, bind_addr="127.0.0.1")
+    pg.init_process_group(0, 1, "rccl", store=store)
+    try:
+        other = C.probe_stream_independence(0, pg.get_comm().comm_stream_handle(), cur, 3.0)
+    finally:
+        pg.destroy_process_group()
+    assert other < 1.5, other
+
+
+def _run_bench_subprocess(extra_env, *extra_args):
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, DIST_QUIET_INIT="1", **extra_env)
+    cmd = [sys.executable, str(root / "bench.py"), "--force-ddp", "--batch-size", "8", "--steps", "2", "--warmup", "2", *extra_args]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_under_the_reducer_in_a_fresh_process():
+    """The production order -- process group first, model afterwards, in a fresh process -- on the full-width
+    GPT-2 under the reducer, with the default (normal priority) and the high-priority communication stream."""
+    line = _run_bench_subprocess({})
+    assert line["config"]["comm"] == "rccl" and line["config"]["comm_stream"]["priority"] == "normal"
+    assert line["config"]["comm_stream"]["independent"] is True
+    assert line["value"] > 0 and line["collectives_per_step"] >= 2
+    line = _run_bench_subprocess({"DIST_COMM_STREAM": "high"})
+    assert line["config"]["comm_stream"]["independent"] is True   # whichever priority the probe settled on
+    assert line["value"] > 0

@@ -58,6 +58,15 @@ def parse_args(argv=None):
     p.add_argument("--force-ddp", action="store_true",
                    help="N = 1: create the process group and wrap the model in the reducer anyway (one-rank RCCL all-reduces on the "
                         "communication stream), to profile the overlap machinery on a single GPU")
+    p.add_argument("--emulate-ranks", type=int, default=0,
+                   help="with --force-ddp on ONE GPU: replace the one-rank all-reduces by a kernel on the communication stream that holds "
+                        "--emulate-wgs workgroups for the time an all-reduce over this many ranks would take at --emulate-busbw (a load "
+                        "model for tuning bucket sizes; the result is labelled emulated and is not a multi-GPU measurement)")
+    p.add_argument("--emulate-busbw", type=float, default=300.0, help="emulated all-reduce bus bandwidth, GB/s")
+    p.add_argument("--emulate-wgs", type=int, default=32, help="workgroups (CUs) the emulated collective keeps resident")
+    p.add_argument("--max-collective-mb", type=float, default=None, help="largest single all-reduce (bigger buckets go out as slices)")
+    p.add_argument("--no-overlap-optimizer", action="store_true",
+                   help="wait for every gradient all-reduce at the end of backward instead of bucket by bucket inside the optimizer step")
     p.add_argument("--trace", action="store_true", help="emit roctx ranges (forward / backward / optimizer) for rocprofv3 --marker-trace")
     p.add_argument("--stock", action="store_true", help="comparison run: stock torch ops and torch.optim.AdamW(fused=True)")
     p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph (default for --model dummy on one GPU, whose step is launch-bound)")
@@ -168,6 +177,12 @@ def run_rank(rank: int, world_size: int, argv):
         ddp_kwargs["reduce_dtype"] = args.reduce_dtype
     if args.bucket_mb:
         ddp_kwargs["bucket_cap_mb"] = args.bucket_mb
+    if args.max_collective_mb:
+        ddp_kwargs["max_collective_mb"] = args.max_collective_mb
+    if args.emulate_ranks > 1:
+        if not (args.force_ddp and world_size <= 1 and use_gpu):
+            raise SystemExit("--emulate-ranks needs --force-ddp on one GPU")
+        pg.get_comm().set_emulation(args.emulate_ranks, args.emulate_busbw, args.emulate_wgs)
     if args.force_ddp and world_size <= 1:
         from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
 
@@ -181,7 +196,8 @@ def run_rank(rank: int, world_size: int, argv):
 
         opt = ShardedOptimizer(model.parameters(), lr=1e-4, weight_decay=0.01, master_weights=(dtype != torch.float32))
     else:
-        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, master_weights=(dtype != torch.float32))
+        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, master_weights=(dtype != torch.float32),
+                         overlap_grad_reduce=not args.no_overlap_optimizer)
 
     if args.trace:
         from distributed_pytorch_amd.utils.timer import range as trace_range
@@ -269,6 +285,9 @@ def run_rank(rank: int, world_size: int, argv):
         "final_loss": round(final_loss, 5),
         "first_loss": round(float(first_loss.detach().float().item()), 5) if first_loss is not None else None,
     }
+    if args.emulate_ranks > 1:
+        result["emulated_allreduce_load"] = {"ranks": args.emulate_ranks, "busbw_gbps": args.emulate_busbw, "workgroups": args.emulate_wgs,
+                                             "note": "one GPU; a stand-in kernel occupies the communication stream, no data crosses a link"}
     if on_rccl:
         info_cs = pg.comm_stream_info() or {}
         result["config"]["comm_stream"] = {k: info_cs.get(k) for k in ("priority", "independent", "candidates_tried")}
@@ -360,6 +379,8 @@ def _overlap_report(pg, step, device, model, n_steps=3):
     if hasattr(model, "bucket_sizes"):
         out["bucket_mib"] = [round(b / 2**20, 1) for b in model.bucket_sizes()]
         out["buckets_rebuilt"] = bool(getattr(model, "buckets_rebuilt", False))
+        out["grads_written_in_place"] = int(model.reducer.num_grads_in_place())
+        out["grads_packed_by_copy"] = int(model.reducer.num_grads_packed())
     return out
 
 

@@ -56,6 +56,9 @@ PYBIND11_MODULE(_C, m) {
              return d;
            })
       .def("aborted", &RcclComm::aborted)
+      .def("set_emulation", &RcclComm::set_emulation, py::arg("ranks"), py::arg("busbw_gbps"), py::arg("workgroups") = 32,
+           py::arg("passes") = 2, py::arg("latency_us") = 30.0)
+      .def("emulating", &RcclComm::emulating)
       .def("group_start", &RcclComm::group_start)
       .def("group_end", &RcclComm::group_end)
       .def("num_async_ops", &RcclComm::num_async_ops)
@@ -121,6 +124,19 @@ PYBIND11_MODULE(_C, m) {
       .def("launch_positions", &Reducer::launch_positions)
       .def("slices_per_bucket", &Reducer::slices_per_bucket)
       .def("globally_unused", &Reducer::globally_unused)
+      .def("take_grad_sink",
+           [](Reducer& r, int64_t i) -> py::object {
+             at::Tensor t = r.take_grad_sink(i);
+             return t.defined() ? py::cast(t) : py::none();
+           })
+      .def("set_deferred_wait", &Reducer::set_deferred_wait, py::arg("on"))
+      .def("deferred_wait", &Reducer::deferred_wait)
+      .def("waits_pending", &Reducer::waits_pending)
+      .def("wait_bucket", &Reducer::wait_bucket, py::arg("bucket"))
+      .def("wait_pending", &Reducer::wait_pending)
+      .def("bucket_of", &Reducer::bucket_of, py::arg("param_index"))
+      .def("num_grads_in_place", &Reducer::num_grads_in_place)
+      .def("num_grads_packed", &Reducer::num_grads_packed)
       .def("broadcast_parameters", &Reducer::broadcast_parameters, py::arg("root") = 0,
            py::call_guard<py::gil_scoped_release>())
       .def("detach", &Reducer::detach);

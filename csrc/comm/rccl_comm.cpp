@@ -1,5 +1,7 @@
 #include "rccl_comm.h"
 
+#include "kernels/kernels.h"
+
 #include <c10/hip/HIPStream.h>
 
 #include <chrono>
@@ -314,7 +316,11 @@ void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
     t0 = timing_event();
     DPA_HIP_CHECK(hipEventRecord(t0, comm_stream_));
   }
-  if (t.numel() > 0) {
+  if (t.numel() > 0 && emulating()) {
+    const double bytes = static_cast<double>(t.numel()) * static_cast<double>(t.element_size());
+    const double ms = 2.0 * (emu_ranks_ - 1) / emu_ranks_ * bytes / (emu_busbw_gbps_ * 1e9) * 1e3 + emu_latency_us_ * 1e-3;
+    kernels::launch_emulated_collective(t.data_ptr(), static_cast<long long>(bytes), emu_workgroups_, emu_passes_, ms, comm_stream_);
+  } else if (t.numel() > 0) {
     std::lock_guard<std::timed_mutex> lk(comm_mu_);
     if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
     DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),
@@ -347,23 +353,33 @@ void RcclComm::broadcast_async(at::Tensor t, int root, int slot) {
 void RcclComm::wait_slot(int slot) {
   if (slot < 0 || static_cast<size_t>(slot) >= slot_events_.size() || !slot_pending_[static_cast<size_t>(slot)]) return;
   DeviceGuard g(device_);
-  DPA_HIP_CHECK(hipStreamWaitEvent(current_stream(device_), slot_events_[static_cast<size_t>(slot)], 0));
+  hipStream_t cur = current_stream(device_);
+  hipEvent_t w0 = nullptr;
+  if (timing_) {  // how long the compute stream is held up by this wait
+    w0 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(w0, cur));
+  }
+  DPA_HIP_CHECK(hipStreamWaitEvent(cur, slot_events_[static_cast<size_t>(slot)], 0));
   slot_pending_[static_cast<size_t>(slot)] = 0;
+  if (w0) {
+    hipEvent_t w1 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(w1, cur));
+    wait_spans_.emplace_back(w0, w1);
+  }
 }
 
 void RcclComm::wait_all_slots() {
-  DeviceGuard g(device_);
-  hipEvent_t w0 = nullptr;
-  if (timing_) {
-    w0 = timing_event();
-    DPA_HIP_CHECK(hipEventRecord(w0, current_stream(device_)));
-  }
   for (size_t i = 0; i < slot_events_.size(); ++i) wait_slot(static_cast<int>(i));
-  if (w0) {
-    hipEvent_t w1 = timing_event();
-    DPA_HIP_CHECK(hipEventRecord(w1, current_stream(device_)));
-    wait_spans_.emplace_back(w0, w1);
-  }
+}
+
+void RcclComm::set_emulation(int ranks, double busbw_gbps, int workgroups, int passes, double latency_us) {
+  if (ranks > 1 && world_ != 1) throw std::runtime_error("RcclComm: the all-reduce stand-in needs a one-rank communicator");
+  if (ranks > 1 && !(busbw_gbps > 0.0)) throw std::runtime_error("RcclComm: emulated bus bandwidth must be positive");
+  emu_ranks_ = ranks;
+  emu_busbw_gbps_ = busbw_gbps;
+  emu_workgroups_ = workgroups > 0 ? workgroups : 32;
+  emu_passes_ = passes > 0 ? passes : 2;
+  emu_latency_us_ = latency_us;
 }
 
 void RcclComm::set_timing(bool on) {

@@ -92,6 +92,14 @@ class RcclComm {
   // True when nothing is queued on the communication stream (blocking check, no event polling).
   bool comm_stream_idle();
 
+  // One-GPU stand-in for a multi-rank all-reduce (experiments only, never a multi-GPU result): while set, the
+  // asynchronous all-reduces of a ONE-rank communicator launch, instead of the library call, a kernel on the
+  // communication stream that keeps `workgroups` workgroups resident for the time an `ranks`-rank all-reduce
+  // of the same bytes would take at `busbw_gbps` bus bandwidth (2 (n-1)/n * bytes / busbw + latency_us) and
+  // moves the buffer `passes` times through HBM meanwhile.  Same fences, events and stream as the real path.
+  void set_emulation(int ranks, double busbw_gbps, int workgroups, int passes, double latency_us);
+  bool emulating() const { return emu_ranks_ > 1; }
+
   // Overlap accounting.  While enabled, every asynchronous collective is bracketed by two
   // timing events on the communication stream and wait_all_slots() by two on the compute
   // stream.  read_timing() waits for them and returns {comm_busy_ms, exposed_ms, n_ops} of
@@ -121,6 +129,8 @@ class RcclComm {
   bool destroyed_ = false;
   bool debug_sync_ = false;
   bool timing_ = false;
+  int emu_ranks_ = 0, emu_workgroups_ = 32, emu_passes_ = 2;
+  double emu_busbw_gbps_ = 0.0, emu_latency_us_ = 30.0;
   std::vector<hipEvent_t> timing_pool_;                       // timing-enabled events, reused
   size_t timing_used_ = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> op_spans_;    // per collective, on the comm stream

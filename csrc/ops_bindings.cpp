@@ -562,7 +562,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> rank1_mlp_backward(Tensor dy, Tensor 
 }
 
 // Gradients of y = x W^T + b given g = dL/d(xW^T+b).  Returns (dx or None, dW, db or None).
-std::tuple<c10::optional<Tensor>, Tensor, c10::optional<Tensor>> linear_backward(Tensor g, Tensor x, Tensor w, bool need_dx, bool need_db) {
+// dw_out: write the weight gradient into this tensor (a slice of a gradient bucket) instead of a fresh one.
+std::tuple<c10::optional<Tensor>, Tensor, c10::optional<Tensor>> linear_backward(Tensor g, Tensor x, Tensor w, bool need_dx, bool need_db,
+                                                                                   c10::optional<Tensor> dw_out) {
   check_gpu(g, "grad");
   check_gpu(x, "x");
   check_gpu(w, "weight");
@@ -574,7 +576,15 @@ std::tuple<c10::optional<Tensor>, Tensor, c10::optional<Tensor>> linear_backward
   const int dt = kdtype(x);
   DevGuard guard(x);
   hipStream_t s = stream_of(x);
-  Tensor dW = at::empty_like(w);
+  Tensor dW;
+  if (dw_out.has_value() && dw_out->defined()) {
+    check_gpu(*dw_out, "dw_out");
+    TORCH_CHECK(dw_out->sizes() == w.sizes() && dw_out->scalar_type() == w.scalar_type() && dw_out->is_contiguous() &&
+                    dw_out->get_device() == w.get_device(), "linear_backward: dw_out must be a contiguous tensor like the weight");
+    dW = *dw_out;
+  } else {
+    dW = at::empty_like(w);
+  }
   c10::optional<Tensor> dx, db;
   if (need_db) db = at::empty({N}, w.options());
   if (need_dx) dx = at::empty_like(x);
@@ -645,7 +655,8 @@ Tensor colsum(Tensor dy) {
 
 // General matrix product on the MFMA kernels (used by tests and benchmarks):
 // C[M,N] = alpha * op(A) op(B)^T with the layout flags of kernels::GemmArgs.
-Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tensor> bias, int64_t act) {
+// out: write C into this [M, N] tensor (e.g. a gradient-bucket slice) instead of allocating it.
+Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tensor> bias, int64_t act, c10::optional<Tensor> out) {
   check_gpu(A, "A");
   check_gpu(B, "B");
   TORCH_CHECK(A.dim() == 2 && B.dim() == 2 && A.scalar_type() == B.scalar_type(), "gemm: 2-D tensors of one dtype expected");
@@ -655,7 +666,15 @@ Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tens
   const int64_t N = b_kmajor ? B.size(0) : B.size(1);
   const int64_t Kb = b_kmajor ? B.size(1) : B.size(0);
   TORCH_CHECK(K == Kb, "gemm: contraction sizes differ (", K, " vs ", Kb, ")");
-  Tensor C = at::empty({M, N}, A.options());
+  Tensor C;
+  if (out.has_value() && out->defined()) {
+    check_gpu(*out, "out");
+    TORCH_CHECK(out->dim() == 2 && out->size(0) == M && out->size(1) == N && out->scalar_type() == A.scalar_type() && out->is_contiguous() &&
+                    out->get_device() == A.get_device(), "gemm: out must be a contiguous [M, N] tensor in the operand dtype");
+    C = *out;
+  } else {
+    C = at::empty({M, N}, A.options());
+  }
   kernels::GemmArgs a{};
   a.A = A.data_ptr(); a.B = B.data_ptr(); a.C = C.data_ptr();
   if (bias.has_value() && bias->defined()) {
@@ -913,13 +932,14 @@ void init_ops(py::module_& m) {
     return linear_route(M, N, K, dt);
   });
   m.def("linear_forward", &linear_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("act") = 0, py::arg("save_pre_act") = false);
-  m.def("linear_backward", &linear_backward, py::arg("grad"), py::arg("x"), py::arg("weight"), py::arg("need_dx") = true, py::arg("need_db") = true);
+  m.def("linear_backward", &linear_backward, py::arg("grad"), py::arg("x"), py::arg("weight"), py::arg("need_dx") = true, py::arg("need_db") = true,
+        py::arg("dw_out") = py::none());
   m.def("rank1_mlp_forward", &rank1_mlp_forward, py::arg("x"), py::arg("w1"), py::arg("b1"), py::arg("W2"), py::arg("b2"), py::arg("act") = 0);
   m.def("rank1_mlp_backward", &rank1_mlp_backward, py::arg("dy"), py::arg("x"), py::arg("w1"), py::arg("b1"), py::arg("W2"), py::arg("act") = 0);
   m.def("act_backward", &act_backward, py::arg("dy"), py::arg("saved"), py::arg("act"), py::arg("need_db") = false);
   m.def("colsum", &colsum);
   m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),
-        py::arg("act") = 0);
+        py::arg("act") = 0, py::arg("out") = py::none());
   m.def("batchnorm_supported", [](int64_t R, int64_t C, const std::string& dtype) {
     return kernels::batchnorm_supported(R, C, dtype == "float32" ? kernels::kF32 : (dtype == "bfloat16" ? kernels::kBF16 : kernels::kF16));
   });

@@ -59,6 +59,11 @@ class RcclTransport final : public Transport {
     comm_->all_reduce(t, static_cast<int>(ncclSum));  // on the current stream; the caller's copy to the host waits for it
   }
   void wait_all() override { comm_->wait_all_slots(); }
+  bool wait_slot(int slot) override {
+    comm_->wait_slot(slot);
+    return true;
+  }
+  bool per_slot_waits() const override { return true; }
   int world() const override { return comm_->world(); }
 
  private:
@@ -207,19 +212,53 @@ void Reducer::detach() {
   hooks_.clear();
 }
 
+void Reducer::wait_bucket(int64_t b) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!waits_pending_ || b < 0 || b >= static_cast<int64_t>(buckets_.size()) || bucket_waited_[static_cast<size_t>(b)]) return;
+  const BucketState& bs = buckets_[static_cast<size_t>(b)];
+  for (size_t k = 0; k < bs.slices.size(); ++k) transport_->wait_slot(bs.slot_base + static_cast<int>(k));
+  bucket_waited_[static_cast<size_t>(b)] = 1;
+}
+
+void Reducer::wait_pending() {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!waits_pending_) return;
+  transport_->wait_all();
+  waits_pending_ = false;
+}
+
 void Reducer::prepare_for_backward(bool sync) {
   std::lock_guard<std::mutex> g(mu_);
+  if (waits_pending_) {  // nobody consumed the deferred waits of the previous pass
+    transport_->wait_all();
+    waits_pending_ = false;
+  }
   armed_ = sync;
   callback_queued_ = false;
   next_bucket_ = 0;
   ready_order_.clear();
   launch_pos_.assign(buckets_.size(), -1);
   had_grad_.assign(params_.size(), 0);
+  sink_taken_.assign(params_.size(), 0);
   for (auto& bs : buckets_) {
     bs.pending = static_cast<int64_t>(bs.spec.param_indices.size());
     bs.launched = false;
     std::fill(bs.ready.begin(), bs.ready.end(), 0);
   }
+}
+
+at::Tensor Reducer::take_grad_sink(int64_t param_index) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!opt_.gradient_as_bucket_view || param_index < 0 || param_index >= static_cast<int64_t>(params_.size())) return at::Tensor();
+  const size_t i = static_cast<size_t>(param_index);
+  const auto loc = locator_[i];
+  if (loc.first < 0 || sink_taken_.size() != params_.size() || sink_taken_[i]) return at::Tensor();
+  const at::Tensor& p = params_[i];
+  BucketState& bs = buckets_[static_cast<size_t>(loc.first)];
+  if (p.grad().defined() || bs.launched || bs.spec.buffer.scalar_type() != p.scalar_type() || !p.is_contiguous()) return at::Tensor();
+  sink_taken_[i] = 1;
+  const size_t j = static_cast<size_t>(loc.second);
+  return bs.spec.buffer.narrow(0, bs.spec.offsets[j], p.numel()).view(p.sizes());
 }
 
 void Reducer::autograd_hook(int64_t param_index) {
@@ -339,9 +378,11 @@ void Reducer::launch_bucket(size_t b) {
       // Accumulated in place inside the bucket (also a gradient kept from earlier no_sync()
       // micro-steps of a parameter that was not used in this one).
       if (pre_divide) v.mul_(scale);
+      ++n_in_place_;
     } else {
       // A gradient that lives outside the arena, produced now or accumulated under no_sync().
       to_copy.push_back(static_cast<int64_t>(j));
+      ++n_packed_;
     }
   }
   pack_into_bucket(bs, to_copy, scale);
@@ -370,7 +411,24 @@ void Reducer::finalize_backward() {
   // still in index order, so the collective sequence is identical on every rank.
   for (size_t b = next_bucket_; b < buckets_.size(); ++b) launch_bucket(b);
   next_bucket_ = buckets_.size();
-  transport_->wait_all();
+  bool all_views = opt_.gradient_as_bucket_view && !opt_.track_unused;
+  if (all_views && defer_wait_ && transport_->per_slot_waits()) {
+    for (auto& bs : buckets_) {
+      for (size_t j = 0; j < bs.spec.param_indices.size() && all_views; ++j) {
+        const at::Tensor& gr = params_[static_cast<size_t>(bs.spec.param_indices[j])].grad();
+        all_views = gr.defined() && gr.data_ptr() == bs.views[j].data_ptr();
+      }
+      if (!all_views) break;
+    }
+  } else {
+    all_views = false;
+  }
+  if (all_views) {
+    waits_pending_ = true;
+    bucket_waited_.assign(buckets_.size(), 0);
+  } else {
+    transport_->wait_all();
+  }
   last_globally_unused_.clear();
   if (opt_.track_unused) {
     // Which parameters got a gradient on at least one rank: sum of the local 0/1 flags.
@@ -385,7 +443,7 @@ void Reducer::finalize_backward() {
     for (size_t i = 0; i < params_.size(); ++i)
       if (locator_[i].first >= 0 && bp[i] == 0) last_globally_unused_.push_back(static_cast<int64_t>(i));
   }
-  if (opt_.unpack_to_grads)
+  if (opt_.unpack_to_grads && !waits_pending_)
     for (auto& bs : buckets_) unpack_from_bucket(bs);
   armed_ = false;
   callback_queued_ = false;

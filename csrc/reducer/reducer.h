@@ -40,6 +40,9 @@ class Transport {
   virtual void all_reduce_sum_blocking(at::Tensor t) = 0;
   // Make the consumer of the buckets (current stream / host thread) wait for all pending ops.
   virtual void wait_all() = 0;
+  // Wait for one slot only; transports that cannot do that return false (the reducer then never defers).
+  virtual bool wait_slot(int /*slot*/) { return false; }
+  virtual bool per_slot_waits() const { return false; }
   virtual int world() const = 0;
 };
 
@@ -95,8 +98,32 @@ class Reducer {
   std::vector<int64_t> slices_per_bucket() const;
   // Parameters that no rank produced a gradient for in the last synchronised backward (track_unused only).
   std::vector<int64_t> globally_unused() const { return last_globally_unused_; }
+  // A fresh view of parameter `param_index`'s slice of its bucket, for an operator that wants to write the
+  // parameter's gradient straight into the arena and return that view as the gradient (autograd then adopts it
+  // as .grad and the bucket needs no pack copy).  Handed out at most once per backward pass and only while the
+  // parameter has no .grad (an existing gradient must be accumulated into, not overwritten); undefined tensor
+  // otherwise -- the caller allocates as usual.
+  at::Tensor take_grad_sink(int64_t param_index);
+  // Gradients found in place in their bucket / copied into it at bucket launch (since construction).
+  int64_t num_grads_in_place() const { return n_in_place_; }
+  int64_t num_grads_packed() const { return n_packed_; }
   // Broadcast every bucket-ordered parameter from `root` (initial parameter sync).
   void broadcast_parameters(int root);
+  // Deferred waits.  Normally the end-of-backward callback makes the compute stream wait for every bucket's
+  // all-reduce, so any kernel queued after backward() sees reduced gradients.  With deferral on, that wait is
+  // left to a consumer that knows the bucket layout (the fused optimizers): it calls wait_bucket(b) right before
+  // it touches bucket b's gradients, so the last buckets' all-reduces run under the update of the first ones.
+  // Only effective when every gradient is a bucket view (nothing to unpack) and the transport has per-slot
+  // events; anything still pending is waited for at the next prepare_for_backward().
+  void set_deferred_wait(bool on) { defer_wait_ = on; }
+  bool deferred_wait() const { return defer_wait_; }
+  bool waits_pending() const { return waits_pending_; }
+  void wait_bucket(int64_t b);
+  void wait_pending();
+  // Bucket index of a parameter (-1: none).
+  int64_t bucket_of(int64_t param_index) const {
+    return param_index >= 0 && param_index < static_cast<int64_t>(locator_.size()) ? locator_[static_cast<size_t>(param_index)].first : -1;
+  }
   // Removes the autograd hooks (also done by the destructor).
   void detach();
 
@@ -135,7 +162,10 @@ class Reducer {
   std::vector<int64_t> ready_order_, last_ready_order_;
   std::vector<int64_t> launch_pos_, last_launch_pos_, last_globally_unused_;
   std::vector<char> had_grad_;  // per parameter: a gradient existed locally when its bucket was launched
-  int64_t n_syncs_ = 0, n_launches_ = 0, n_pack_launches_ = 0, n_collectives_ = 0;
+  bool defer_wait_ = false, waits_pending_ = false;
+  std::vector<char> bucket_waited_;
+  std::vector<char> sink_taken_;  // per parameter: its bucket slice was handed out as a gradient sink in this pass
+  int64_t n_syncs_ = 0, n_launches_ = 0, n_pack_launches_ = 0, n_collectives_ = 0, n_in_place_ = 0, n_packed_ = 0;
 };
 
 }  // namespace dpa

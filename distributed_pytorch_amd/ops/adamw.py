@@ -42,7 +42,7 @@ def _flat_dense(t: torch.Tensor) -> torch.Tensor:
 
 class FusedAdamW(Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 master_weights: bool = False, max_grad_norm: Optional[float] = None):
+                 master_weights: bool = False, max_grad_norm: Optional[float] = None, overlap_grad_reduce: bool = False):
         if lr < 0.0:
             raise ValueError(f"Invalid learning rate: {lr}")
         if eps < 0.0:
@@ -55,6 +55,10 @@ class FusedAdamW(Optimizer):
         super().__init__(params, defaults)
         self.master_weights = bool(master_weights)
         self.max_grad_norm = max_grad_norm
+        # Under the data-parallel wrapper: wait for the gradient all-reduces bucket by bucket inside step(), in
+        # bucket order, instead of all at once at the end of backward(), so the last all-reduces of a step run
+        # under the update of the first buckets (parallel/ddp.py: enable_deferred_gradient_wait).
+        self.overlap_grad_reduce = bool(overlap_grad_reduce)
         # Parameters whose gradients define the global norm for clipping; None = this optimizer's own.  A sharded
         # optimizer that updates a subset of the model sets it to all parameters (parallel/zero.py).
         self.clip_params: Optional[List[torch.Tensor]] = None
@@ -151,6 +155,12 @@ class FusedAdamW(Optimizer):
             return loss
         C = _ext.C()
         grad_scale = None
+        ddp = self._wrapper_of(gpu_groups[0][2]) if self.overlap_grad_reduce else None
+        if ddp is not None and not ddp.reducer.deferred_wait():
+            ddp.enable_deferred_gradient_wait(True)   # takes effect from the next backward pass on
+        if ddp is not None and (self.max_grad_norm is not None or not ddp.reducer.waits_pending()):
+            ddp.wait_for_gradients()                  # the global norm needs every gradient
+            ddp = None
         if self.max_grad_norm is not None:
             over = self.clip_params if self.clip_params is not None else [p for _, _, ps in gpu_groups for p in ps]
             grad_scale = self._clip_coefficient(C, [p.grad for p in over if p.grad is not None and p.is_cuda])
@@ -162,27 +172,56 @@ class FusedAdamW(Optimizer):
                 if p not in self._step_i:
                     self._step_i[p] = int(st["step"].item())  # restored or fresh; read once, then mirrored as an int
                 cohorts.setdefault(ticks - self._step_i[p], []).append((p, st))
-            for origin, members in cohorts.items():
+            for origin, all_members in cohorts.items():
                 hp = self._device_hparams((gi, origin), group, ps[0].device, ticks - origin)
                 C.adamw_tick(hp)
-                pv, gv, mv, vv, wv = [], [], [], [], []
-                for p, st in members:
-                    g = p.grad
-                    if not _is_dense(p):
-                        raise RuntimeError("FusedAdamW: parameters must be dense (contiguous in some memory format)")
-                    if g.stride() != p.stride():
-                        g = torch.empty_like(p).copy_(g)  # bring the gradient into the parameter's element order
-                    pv.append(_flat_dense(p))
-                    gv.append(_flat_dense(g))
-                    mv.append(_flat_dense(st["exp_avg"]))
-                    vv.append(_flat_dense(st["exp_avg_sq"]))
-                    wv.append(_flat_dense(st["master"]) if "master" in st else None)
-                C.adamw_step(pv, gv, mv, vv, wv, hp, grad_scale)
-                for p, st in members:
-                    st["step"] += 1
-                    self._step_i[p] += 1
+                for bucket, members in self._by_bucket(ddp, all_members):
+                    if bucket is not None:
+                        ddp.wait_bucket(bucket)
+                    self._update(C, members, hp, grad_scale)
             self._ticks[gi] = ticks + 1
+        if ddp is not None:
+            ddp.wait_for_gradients()   # buckets none of whose parameters were updated here
         return loss
+
+    def _update(self, C, members, hp, grad_scale) -> None:
+        pv, gv, mv, vv, wv = [], [], [], [], []
+        for p, st in members:
+            g = p.grad
+            if not _is_dense(p):
+                raise RuntimeError("FusedAdamW: parameters must be dense (contiguous in some memory format)")
+            if g.stride() != p.stride():
+                g = torch.empty_like(p).copy_(g)  # bring the gradient into the parameter's element order
+            pv.append(_flat_dense(p))
+            gv.append(_flat_dense(g))
+            mv.append(_flat_dense(st["exp_avg"]))
+            vv.append(_flat_dense(st["exp_avg_sq"]))
+            wv.append(_flat_dense(st["master"]) if "master" in st else None)
+        C.adamw_step(pv, gv, mv, vv, wv, hp, grad_scale)
+        for p, st in members:
+            st["step"] += 1
+            self._step_i[p] += 1
+
+    @staticmethod
+    def _wrapper_of(params):
+        for p in params:
+            ref = getattr(p, "_dpa_ddp", None)
+            if ref is not None:
+                return ref[0]()
+        return None
+
+    @staticmethod
+    def _by_bucket(ddp, members):
+        """``members`` split by gradient bucket, in bucket (= all-reduce launch) order; one group without a
+        bucket when the deferred waits are not in use."""
+        if ddp is None:
+            return [(None, members)]
+        groups: Dict[int, list] = {}
+        for p, st in members:
+            ref = getattr(p, "_dpa_ddp", None)
+            b = ddp.bucket_of(ref[1]) if ref is not None and ref[0]() is ddp else -1
+            groups.setdefault(b, []).append((p, st))
+        return [(b if b >= 0 else None, groups[b]) for b in sorted(groups)]
 
     def _clip_coefficient(self, C, grads: List[torch.Tensor]) -> torch.Tensor:
         dev = grads[0].device

@@ -67,7 +67,7 @@ class _ProjFlashQKV(torch.autograd.Function):
         dqkv, db = C.attention_backward(d_o, qkv, o, lse, ctx.n_head, ctx.scale, True)
         g = dqkv.view(-1, dqkv.shape[-1])
         dx = gemm.nn(g, w, ctx.impl) if ctx.needs_input_grad[0] else None
-        return dx, gemm.tn(g, x2, ctx.impl), db, None, None, None, None, None
+        return dx, gemm.weight_grad(g, x2, w, ctx.impl), db, None, None, None, None, None
 
 
 _BLOCK_ROWS = 128  # rows per query / key block of the kernels

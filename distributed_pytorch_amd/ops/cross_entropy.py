@@ -83,7 +83,7 @@ class _ProjectionXent(torch.autograd.Function):
             dx = gemm.nn(dlogits, weight, ctx.impl).mul_(g)
         if ctx.needs_input_grad[1]:
             # [vocabulary, K] with the whole token count as contraction
-            dw = gemm.tn(dlogits, x2, ctx.impl).mul_(g)
+            dw = gemm.weight_grad(dlogits, x2, weight, ctx.impl).mul_(g)
         return dx, dw, None, None, None, None, None
 
 

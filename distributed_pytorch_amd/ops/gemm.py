@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _ext
+from .grad_sink import weight_grad_buffer
 
 _NAMES = {torch.float32: "float32", torch.bfloat16: "bfloat16"}
 
@@ -49,8 +50,20 @@ def nn(g: torch.Tensor, w: torch.Tensor, impl: str = "native") -> torch.Tensor:
     return g @ w
 
 
-def tn(g: torch.Tensor, x: torch.Tensor, impl: str = "native") -> torch.Tensor:
-    """g [M, N]^T @ x [M, K]: the whole row count is the contraction (split over the chip when the output has few tiles)."""
+def tn(g: torch.Tensor, x: torch.Tensor, impl: str = "native", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g [M, N]^T @ x [M, K]: the whole row count is the contraction (split over the chip when the output has few tiles).
+    ``out``: a contiguous [N, K] tensor to write into (a gradient-bucket slice, see ``grad_sink.py``)."""
     if impl == "native" and native_ok(g, x, g.shape[1], x.shape[1], g.shape[0], False, False):
-        return _ext.C().gemm(g, x, False, False)
+        return _ext.C().gemm(g, x, False, False, None, 0, out)
+    if out is not None:
+        return torch.mm(g.t(), x, out=out)
     return g.t() @ x
+
+
+def weight_grad(g: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, impl: str = "native") -> torch.Tensor:
+    """dW = g^T x for ``weight``, written straight into the parameter's gradient-bucket slice when the
+    data-parallel wrapper offers one."""
+    out = weight_grad_buffer(weight)
+    if out is not None and (out.shape != (g.shape[1], x.shape[1]) or out.dtype != g.dtype):
+        out = None
+    return tn(g, x, impl, out)

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _ext
+from .grad_sink import weight_grad_buffer
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 _ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
@@ -81,9 +82,9 @@ class _LinearBiasAct(torch.autograd.Function):
         if ctx.act != ACT_NONE:
             # g = dy * act'(.) and the bias gradient come out of one pass over dy.
             g, db = C.act_backward(dy, saved, ctx.act, ctx.has_bias)
-            dx, dw, _ = C.linear_backward(g, x, weight, need_dx, False)
+            dx, dw, _ = C.linear_backward(g, x, weight, need_dx, False, weight_grad_buffer(weight))
         else:
-            dx, dw, db = C.linear_backward(dy, x, weight, need_dx, ctx.has_bias)
+            dx, dw, db = C.linear_backward(dy, x, weight, need_dx, ctx.has_bias, weight_grad_buffer(weight))
         return dx, dw, (db if ctx.has_bias else None), None
 
 

@@ -51,10 +51,10 @@ class _FusedMLP(torch.autograd.Function):
         x2, w_fc, w_proj, aux, h = ctx.saved_tensors
         dy = dy.contiguous()
         g, db_fc = C.dgrad_act_backward(dy, w_proj, aux, ctx.act, True)
-        dw_proj = gemm.tn(dy, h, ctx.impl)
+        dw_proj = gemm.weight_grad(dy, h, w_proj, ctx.impl)
         db_proj = C.colsum(dy) if ctx.has_b_proj else None
         dx = gemm.nn(g, w_fc, ctx.impl) if ctx.needs_input_grad[0] else None
-        dw_fc = gemm.tn(g, x2, ctx.impl)
+        dw_fc = gemm.weight_grad(g, x2, w_fc, ctx.impl)
         return dx, dw_fc, db_fc, dw_proj, db_proj, None, None
 
 

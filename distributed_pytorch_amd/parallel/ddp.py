@@ -39,11 +39,21 @@ def _mb_env(name: str, default_mb: float) -> int:
     return int(float(v if v not in (None, "") else default_mb) * (1 << 20))
 
 
-def default_bucket_bytes() -> int:
-    """Steady-state bucket size.  On an 8-GPU xGMI mesh each of the 7 links carries 1/8 of
-    a bucket per direct reduce-scatter / all-gather step, so buckets are larger than the
-    25 MiB NVLink-era default: 64 MiB leaves 8 MiB per link per step."""
-    return _mb_env("DIST_BUCKET_MB", 64)
+def default_bucket_bytes(total_grad_bytes: Optional[int] = None) -> int:
+    """Steady-state bucket size: ``DIST_BUCKET_MB`` when set, otherwise a quarter of the model's gradient
+    bytes clamped to [32, 256] MiB.  On an 8-GPU xGMI mesh each of the 7 links carries 1/8 of a bucket per
+    direct reduce-scatter / all-gather step, so buckets are much larger than the 25 MiB NVLink-era default;
+    measured with the one-GPU 8-rank load model (``bench.py --emulate-ranks 8``, 300 GB/s bus bandwidth,
+    ``profiles/emulated_allreduce_load.md``): Wide MLP (1.09 GB of gradients) 32 / 64 / 128 / 256 MiB caps ->
+    90.8 / 91.8 / 93.2 / 95.0 % of the unwrapped step rate once the optimizer waits bucket by bucket, because the
+    tail of the last bucket is hidden under the update of the earlier ones and fewer, larger collectives cost
+    less launch and scheduling time; GPT-2 small (248 MB) stays at 62 MiB, 99.6 %."""
+    v = os.environ.get("DIST_BUCKET_MB")
+    if v not in (None, ""):
+        return int(float(v) * (1 << 20))
+    if total_grad_bytes is None:
+        return 64 << 20
+    return int(min(256 << 20, max(32 << 20, total_grad_bytes // 4)))
 
 
 def default_first_bucket_bytes() -> int:
@@ -125,7 +135,8 @@ class DistributedDataParallel(nn.Module):
         self.reduce_dtype = reduce_dtype
 
         self._verify_replicas()
-        self._bucket_bytes = int(bucket_cap_mb * (1 << 20)) if bucket_cap_mb is not None else default_bucket_bytes()
+        total_grad_bytes = sum(p.numel() * torch.empty((), dtype=self._bucket_dtype(p)).element_size() for p in self._params)
+        self._bucket_bytes = int(bucket_cap_mb * (1 << 20)) if bucket_cap_mb is not None else default_bucket_bytes(total_grad_bytes)
         self._first_bucket_bytes = int(first_bucket_mb * (1 << 20)) if first_bucket_mb is not None else default_first_bucket_bytes()
         self._max_collective_bytes = (int(max_collective_mb * (1 << 20)) if max_collective_mb is not None
                                       else default_max_collective_bytes(self._bucket_bytes))
@@ -139,6 +150,24 @@ class DistributedDataParallel(nn.Module):
         self._carried_syncs = 0      # counters of reducers retired by a rebuild
         self._carried_launches = 0
         self._build_buckets(None)
+        if self._grad_as_view:
+            # Operators with their own weight-gradient kernels write straight into the parameter's bucket slice
+            # (ops/grad_sink.py); the lookup goes through self._reducer, so it survives a bucket re-plan.
+            import weakref
+
+            from ..ops import grad_sink
+
+            me = weakref.ref(self)
+
+            def provider(i):
+                def take():
+                    ddp = me()
+                    return ddp._reducer.take_grad_sink(i) if ddp is not None else None
+                return take
+
+            for i, p in enumerate(self._params):
+                grad_sink.register(p, provider(i))
+                p._dpa_ddp = (me, i)   # lets a fused optimizer find the wrapper and the parameter's bucket
         self._flatten_buffers()
         if init_sync and self.world_size > 1:
             self._reducer.broadcast_parameters(0)
@@ -193,6 +222,7 @@ class DistributedDataParallel(nn.Module):
         self._bucket_params = [list(b.param_indices) for b in plan.buckets]
         self._reducer = self._C.Reducer(self._params, specs, self._transport, self._grad_as_view, True,
                                         int(self._max_collective_bytes), self.find_unused_parameters and self.world_size > 1)
+        self._reducer.set_deferred_wait(getattr(self, "_defer_wait", False))
 
     def _agreed_ready_order(self) -> List[int]:
         """Rank 0's observed gradient-ready order, on every rank (the layouts must be identical)."""
@@ -295,6 +325,27 @@ class DistributedDataParallel(nn.Module):
             yield
         finally:
             self.require_backward_grad_sync = old
+
+    # ------------------------------------------------------------------ deferred gradient waits
+    def enable_deferred_gradient_wait(self, on: bool = True) -> None:
+        """Leaves the wait for the buckets' all-reduces to the optimizer.  By default ``backward()`` returns with
+        the compute stream already ordered behind every all-reduce.  With this on (``FusedAdamW`` /
+        ``ShardedOptimizer`` with ``overlap_grad_reduce=True`` switch it on themselves) the optimizer waits
+        bucket by bucket, right before it updates a bucket's parameters, so the last all-reduces of a step run
+        under the update of the first buckets.  Anything else that reads ``.grad`` between ``backward()`` and
+        ``step()`` must call ``wait_for_gradients()`` first."""
+        self._defer_wait = bool(on)
+        self._reducer.set_deferred_wait(self._defer_wait)
+
+    def wait_for_gradients(self) -> None:
+        """The current stream waits for every gradient all-reduce still in flight (no-op when none is)."""
+        self._reducer.wait_pending()
+
+    def wait_bucket(self, bucket: int) -> None:
+        self._reducer.wait_bucket(int(bucket))
+
+    def bucket_of(self, param_index: int) -> int:
+        return int(self._reducer.bucket_of(int(param_index)))
 
     # ------------------------------------------------------------------ introspection
     @property

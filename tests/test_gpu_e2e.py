@@ -598,3 +598,49 @@ def test_bench_under_the_reducer_in_a_fresh_process():
     line = _run_bench_subprocess({"DIST_COMM_STREAM": "high"})
     assert line["config"]["comm_stream"]["independent"] is True   # whichever priority the probe settled on
     assert line["value"] > 0
+
+
+def test_weight_gradients_land_in_the_bucket_and_optimizer_waits_per_bucket(rccl_group):
+    """Operators with their own weight-gradient kernels write straight into the parameter's bucket slice (no pack
+    copy for those tensors), and ``FusedAdamW(overlap_grad_reduce=True)`` takes over the waits for the all-reduces
+    bucket by bucket; five steps still give exactly the weights of unwrapped training."""
+    from distributed_pytorch_amd.models import GPT2, GPT2Config
+    from distributed_pytorch_amd.ops import FusedAdamW
+    from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+    cfg = GPT2Config(block_size=256, vocab_size=1024, n_layer=2, n_head=2, n_embd=128)
+    torch.manual_seed(0)
+    plain = GPT2(cfg).to(DEV).bfloat16()
+    twin = GPT2(cfg).to(DEV).bfloat16()
+    twin.load_state_dict(plain.state_dict())
+    ddp = DistributedDataParallel(twin, device_ids=[0], bucket_cap_mb=0.25, first_bucket_mb=0.05)
+    o1 = FusedAdamW(plain.parameters(), 1e-3, master_weights=True)
+    o2 = FusedAdamW(ddp.parameters(), 1e-3, master_weights=True, overlap_grad_reduce=True)
+    g = torch.Generator().manual_seed(1)
+    pending = []
+    for step in range(5):
+        idx = torch.randint(0, 1024, (4, 256), generator=g).to(DEV)
+        tgt = torch.randint(0, 1024, (4, 256), generator=g).to(DEV)
+        for model, opt in ((plain, o1), (ddp, o2)):
+            opt.zero_grad(set_to_none=True)
+            loss = model(idx, tgt)
+            loss.backward()
+            if model is ddp:
+                pending.append(bool(ddp.reducer.waits_pending()))
+            opt.step()
+            if model is ddp:
+                assert not ddp.reducer.waits_pending()
+    # the optimizer switched the deferral on in its first step; from the second backward on the waits are its own
+    assert pending == [False, True, True, True, True], pending
+    n_weights = sum(1 for n, p in ddp.module.named_parameters() if p.dim() == 2 and "wpe" not in n)
+    assert ddp.reducer.num_grads_in_place() >= 4 * (n_weights - 1), (ddp.reducer.num_grads_in_place(), n_weights)
+    for (n, a), b in zip(plain.named_parameters(), ddp.module.parameters()):
+        assert torch.equal(a, b), n
+    # a consumer that is not the optimizer asks for the gradients explicitly
+    ddp.zero_grad(set_to_none=True)
+    ddp(idx, tgt).backward()
+    assert ddp.reducer.waits_pending()
+    ddp.wait_for_gradients()
+    assert not ddp.reducer.waits_pending()
+    total = torch.stack([p.grad.float().norm() for p in ddp.parameters()]).sum().item()
+    assert total == total and total > 0

@@ -103,7 +103,8 @@ def build_workload(args, device):
         tgt = torch.randint(0, cfg.vocab_size, (B, T), generator=g).to(device)
         loss_fn = lambda m: m(idx, tgt)
         info = dict(model="gpt2-small" if name == "gpt2" else "gpt2-medium", seq_len=T, params=model.num_parameters(),
-                    flops_per_sample=model.flops_per_token(T) * T, tokens_per_sample=T)
+                    flops_per_sample=model.flops_per_token(T) * T, tokens_per_sample=T,
+                    flops_per_sample_noncausal=model.flops_per_token(T, causal=False) * T)
         return model, loss_fn, B, dtype, info
     if name == "widemlp":
         dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
@@ -281,10 +282,14 @@ def run_rank(rank: int, world_size: int, argv):
             "hip_graph": bool(graph is not None),
         },
         "tokens_per_sec": round(samples_per_sec * info["tokens_per_sample"], 1),
+        # FLOPs the kernels execute (causal attention counted as half the full score matrix)
         "model_tflops_per_gpu": round(info["flops_per_sample"] * per_gpu_batch / (ms * 1e-3) / 1e12, 2),
         "final_loss": round(final_loss, 5),
         "first_loss": round(float(first_loss.detach().float().item()), 5) if first_loss is not None else None,
     }
+    if "flops_per_sample_noncausal" in info:  # the convention that charges every query the whole sequence
+        result["model_tflops_per_gpu_full_attention_convention"] = round(
+            info["flops_per_sample_noncausal"] * per_gpu_batch / (ms * 1e-3) / 1e12, 2)
     if args.emulate_ranks > 1:
         result["emulated_allreduce_load"] = {"ranks": args.emulate_ranks, "busbw_gbps": args.emulate_busbw, "workgroups": args.emulate_wgs,
                                              "note": "one GPU; a stand-in kernel occupies the communication stream, no data crosses a link"}

@@ -178,11 +178,15 @@ class GPT2(nn.Module):
     def num_parameters(self) -> int:
         return sum(p.numel() for p in self.parameters())
 
-    def flops_per_token(self, seq_len: int) -> float:
-        """Training FLOPs per token: 6 * (non-embedding params + lm_head) + attention."""
+    def flops_per_token(self, seq_len: int, causal: bool = True) -> float:
+        """Training FLOPs per token: 6 * (non-embedding params + lm_head) + attention.  The attention term is
+        12 * L * C * T when every query is charged the full sequence (the usual "model FLOPs" convention) and
+        half of that for the products a causal kernel really executes (``causal=True``, the default: what the
+        hardware does here)."""
         cfg = self.cfg
         n = sum(p.numel() for name, p in self.named_parameters() if not name.startswith("wpe"))
-        return 6.0 * n + 12.0 * cfg.n_layer * cfg.n_embd * seq_len
+        attn = 12.0 * cfg.n_layer * cfg.n_embd * seq_len
+        return 6.0 * n + (0.5 * attn if causal else attn)
 
     def forward(self, idx: torch.Tensor, targets: Optional[torch.Tensor] = None):
         B, T = idx.shape

@@ -36,7 +36,7 @@ class _Rank1MLP(torch.autograd.Function):
 
 
 def rank1_mlp_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, act) -> bool:
-    return (x.is_cuda and x.dim() == 2 and x.shape[1] == 1 and w1.shape[1] == 1 and w2.shape[0] <= 16 and not x.requires_grad
+    return (_ext.have_C() and x.is_cuda and w1.is_cuda and w2.is_cuda and x.dim() == 2 and x.shape[1] == 1 and w1.shape[1] == 1 and w2.shape[0] <= 16 and not x.requires_grad
             and x.dtype == w1.dtype == w2.dtype and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
             and _act_code(act) in (ACT_NONE, ACT_RELU))
 

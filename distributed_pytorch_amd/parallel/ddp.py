@@ -26,8 +26,18 @@ from . import process_group as pg
 
 _REDUCE_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
                   "fp16": torch.float16, "float16": torch.float16}
-_IGNORED_KWARGS = ("output_device", "dim", "check_reduction", "static_graph", "delay_all_reduce_named_params",
-                   "param_to_hook_all_reduce", "mixed_precision", "device_mesh", "skip_all_reduce_unused_params")
+# Accepted and without effect here: they describe where torch's wrapper puts outputs / how it checks itself.
+_IGNORED_KWARGS = ("output_device", "dim", "check_reduction", "device_mesh", "skip_all_reduce_unused_params")
+# Accepted, but they ask torch's wrapper for behaviour this one does not have: said once, on stderr of rank 0.
+_WARNED_KWARGS = {
+    "static_graph": "the bucket layout is re-planned once from the observed gradient order in any case; nothing else "
+                    "of torch's static-graph mode (activation-checkpoint re-entrancy, delayed all-reduce) exists here",
+    "delay_all_reduce_named_params": "every parameter is reduced inside backward; none is delayed",
+    "param_to_hook_all_reduce": "every parameter is reduced inside backward; none is delayed",
+    "mixed_precision": "use reduce_dtype= (gradient all-reduce dtype) and keep bf16 parameters with fp32 master weights "
+                       "in the optimizer (FusedAdamW(master_weights=True)) instead",
+}
+_warned_once = set()
 # Positional order of torch's DistributedDataParallel after (module, device_ids): the reference forwards
 # ``*args`` to it untouched (reference distributed.py:112-114), so the same call must bind the same way here.
 _TORCH_POSITIONAL = ("output_device", "dim", "broadcast_buffers", "init_sync", "process_group", "bucket_cap_mb",
@@ -88,14 +98,22 @@ class DistributedDataParallel(nn.Module):
             bucket_cap_mb = given.pop("bucket_cap_mb", bucket_cap_mb)
             find_unused_parameters = given.pop("find_unused_parameters", find_unused_parameters)
             gradient_as_bucket_view = given.pop("gradient_as_bucket_view", gradient_as_bucket_view)
-            kwargs.update(given)  # output_device, dim, check_reduction, static_graph: accepted, no effect here
+            kwargs.update(given)  # output_device, dim, check_reduction, static_graph: handled with the keywords below
         for k in list(kwargs):
             if k in _IGNORED_KWARGS:
                 kwargs.pop(k)
+            elif k in _WARNED_KWARGS:
+                v = kwargs.pop(k)
+                if v not in (None, False) and k not in _warned_once:
+                    _warned_once.add(k)
+                    warnings.warn(f"DistributedDataParallel({k}=...) is accepted for compatibility and has no effect: {_WARNED_KWARGS[k]}",
+                                  stacklevel=3)
         if kwargs:
             raise TypeError(f"DistributedDataParallel: unexpected keyword argument(s) {sorted(kwargs)}")
-        if process_group is not None:
-            warnings.warn("process_group= is ignored: the default group of distributed.init_process_group is used")
+        if process_group is not None and "process_group" not in _warned_once:
+            _warned_once.add("process_group")
+            warnings.warn("DistributedDataParallel(process_group=...) is ignored: gradients are reduced over the group of "
+                          "distributed.init_process_group (all ranks)", stacklevel=2)
         self.module = module
         self.device_ids = device_ids  # accepted for API compatibility; the module's own device is used
         self.broadcast_buffers = bool(broadcast_buffers)
@@ -326,6 +344,57 @@ class DistributedDataParallel(nn.Module):
         finally:
             self.require_backward_grad_sync = old
 
+    # ------------------------------------------------------------------ torch-DDP surface beyond forward / no_sync
+    def register_comm_hook(self, state, hook) -> None:
+        """torch's hook signature is ``hook(state, bucket) -> Future``, built on c10d work objects that do not exist
+        on this data plane.  What the stock hooks are used for is available directly: the built-in names
+        ``"bf16_compress"`` / ``"fp16_compress"`` (or torch's ``bf16_compress_hook`` / ``fp16_compress_hook``
+        functions themselves) switch the gradient all-reduce to that dtype -- buckets are re-allocated in it and
+        the pack kernel casts on the way in -- and ``"allreduce"`` / ``allreduce_hook`` restores the parameter
+        dtype.  Any other callable raises."""
+        name = hook if isinstance(hook, str) else getattr(hook, "__name__", "")
+        table = {"bf16_compress": torch.bfloat16, "bf16_compress_hook": torch.bfloat16, "fp16_compress": torch.float16,
+                 "fp16_compress_hook": torch.float16, "allreduce": None, "allreduce_hook": None}
+        if name not in table:
+            raise NotImplementedError(
+                f"register_comm_hook: arbitrary communication hooks ({name or hook!r}) are not supported; built in are "
+                "'allreduce', 'bf16_compress' and 'fp16_compress' (or the torch functions of those names); for anything else "
+                "reduce the gradients yourself under no_sync()")
+        if self._reducer.num_backward_syncs() + self._carried_syncs > 0 and self._reducer.waits_pending():
+            self._reducer.wait_pending()
+        self.reduce_dtype = table[name]
+        old = self._reducer
+        old.detach()
+        self._carried_syncs += int(old.num_backward_syncs())
+        self._carried_launches += int(old.num_bucket_launches())
+        grads = [p.grad for p in self._params]
+        for p in self._params:
+            p.grad = None          # views of the arenas that are about to be replaced
+        self._build_buckets([i for b in self._bucket_params for i in b] if self.buckets_rebuilt else None)
+        for p, g in zip(self._params, grads):
+            if g is not None:
+                p.grad = g.clone()
+
+    @contextlib.contextmanager
+    def join(self, divide_by_initial_world_size: bool = True, enable: bool = True, throw_on_early_termination: bool = False):
+        """torch's ``join()`` lets ranks with fewer batches leave early while the others keep reducing.  Here every
+        rank must run the same number of synchronised backward passes (the sampler pads shards to equal length, as
+        the reference's ``DistributedSampler`` does), so the context only checks that on exit: a rank that ran a
+        different number of passes than its peers raises instead of leaving the others hanging in a collective."""
+        start = self.num_backward_syncs()
+        yield self
+        if not enable or self.world_size == 1:
+            return
+        n = torch.tensor([self.num_backward_syncs() - start], dtype=torch.int64)
+        lo, hi = n.clone(), n.clone()
+        if pg.is_initialized() and pg.get_backend() == "rccl":
+            lo, hi = lo.to(self.device), hi.to(self.device)
+        pg.all_reduce(lo, "min")
+        pg.all_reduce(hi, "max")
+        if int(lo.item()) != int(hi.item()):
+            raise RuntimeError(f"join(): ranks ran between {int(lo.item())} and {int(hi.item())} synchronised backward passes; "
+                               "uneven inputs are not supported -- give every rank the same number of batches")
+
     # ------------------------------------------------------------------ deferred gradient waits
     def enable_deferred_gradient_wait(self, on: bool = True) -> None:
         """Leaves the wait for the buckets' all-reduces to the optimizer.  By default ``backward()`` returns with
@@ -369,14 +438,50 @@ class DistributedDataParallel(nn.Module):
         return repr(self._plan)
 
     def parameter_checksum(self) -> torch.Tensor:
-        """Sum of all parameters in fp64, for divergence checks across ranks."""
+        """Sum of all parameters in fp64 (a cheap drift indicator; equal sums do not prove equal parameters)."""
         with torch.no_grad():
             return torch.stack([p.detach().double().sum() for p in self._params]).sum()
 
+    def parameter_hashes(self) -> torch.Tensor:
+        """One 64-bit value per parameter computed from its exact bit pattern: the raw bytes, read as integers,
+        are weighted by position-dependent odd multipliers and summed with wrap-around, so a changed bit, two
+        swapped elements or two errors that cancel in a plain sum all change the value."""
+        out = []
+        with torch.no_grad():
+            for p in self._params:
+                t = p.detach().contiguous().view(-1)
+                if t.element_size() == 2:
+                    bits = t.view(torch.int16).to(torch.int64) & 0xFFFF
+                elif t.element_size() == 4:
+                    bits = t.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+                else:
+                    bits = t.view(torch.uint8).to(torch.int64)
+                k = torch.arange(bits.numel(), device=bits.device, dtype=torch.int64)
+                weights = (k * 2654435761 + 0x9E3779B97F4A7C15 % (1 << 62)) | 1
+                out.append((bits * weights).sum() + bits.numel())
+        return torch.stack(out)
+
     def check_replicas_in_sync(self, rtol: float = 0.0) -> bool:
-        """All ranks compare a parameter checksum (the debug aid for stream / bucket races)."""
-        c = self.parameter_checksum().to(torch.float64)
-        lo, hi = c.clone(), c.clone()
+        """True when every rank holds bit-identical parameters: the per-parameter bit-pattern hashes
+        (``parameter_hashes``) are compared across ranks with a min / max all-reduce.  ``rtol`` > 0 falls back to
+        the tolerance check on the fp64 checksum (replicas that are allowed to differ in the last bits)."""
+        if rtol > 0.0:
+            c = self.parameter_checksum().to(torch.float64)
+            lo, hi = c.clone(), c.clone()
+            pg.all_reduce(lo, "min")
+            pg.all_reduce(hi, "max")
+            return bool((hi - lo).abs() <= rtol * hi.abs())
+        h = self.parameter_hashes()
+        lo, hi = h.clone(), h.clone()
         pg.all_reduce(lo, "min")
         pg.all_reduce(hi, "max")
-        return bool((hi - lo).abs() <= rtol * hi.abs())
+        return bool(torch.equal(lo.cpu(), hi.cpu()))
+
+    def diverged_parameters(self) -> List[str]:
+        """Names of the parameters whose bit patterns differ between ranks (collective)."""
+        h = self.parameter_hashes()
+        lo, hi = h.clone(), h.clone()
+        pg.all_reduce(lo, "min")
+        pg.all_reduce(hi, "max")
+        bad = (lo != hi).cpu().tolist()
+        return [n for n, b in zip(self._param_names, bad) if b]

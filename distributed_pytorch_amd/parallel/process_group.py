@@ -51,6 +51,8 @@ class _State:
     monitor_stop: Optional[threading.Event] = None
     monitor_store: Optional[Store] = None
     old_sigterm: object = None
+    wakeup_pipe: Optional[tuple] = None
+    wakeup_prev_fd: Optional[int] = None
     comm_stream_info: Optional[dict] = None  # how the communication stream was chosen (RcclComm.comm_stream_info)
 
 
@@ -321,6 +323,7 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
     st.barrier(f"init/{gen}", world_size, timeout_s)
     if world_size > 1:
         _start_hang_detection(state)
+    _install_sigterm_abort(state)
 
 
 def _start_hang_detection(state: "_State") -> None:
@@ -344,22 +347,77 @@ def _start_hang_detection(state: "_State") -> None:
             os._exit(hb.EXIT_CODE_ABORTED)
 
         state.monitor_stop = mon.watch_in_thread(on_hang)
-    if state.comm is not None and threading.current_thread() is threading.main_thread():
-        # SIGTERM (launcher teardown) aborts the communicator first, so kernels of a collective
-        # that a peer never joined are released before the process goes away.
-        def _on_term(signum, frame):
-            abort()
-            prev = state.old_sigterm
-            if callable(prev):
-                prev(signum, frame)
-            else:
-                signal.signal(signal.SIGTERM, signal.SIG_DFL)
-                os.kill(os.getpid(), signal.SIGTERM)
 
+
+def _install_sigterm_abort(state: "_State") -> None:
+    """SIGTERM (launcher teardown, a scheduler's time limit) aborts the communicator first, so kernels of a
+    collective that a peer never joined are released before the process goes away.  A Python-level handler alone
+    would only run when the main thread returns to the interpreter -- never, for a rank blocked inside a native
+    wait on a hung collective -- so the signal is also written to a wake-up descriptor that a small thread reads:
+    if the process is still there a second after SIGTERM arrived, that thread aborts the communicator and ends the
+    process with the status of a SIGTERM death itself."""
+    if state.comm is None or threading.current_thread() is not threading.main_thread():
+        return
+
+    def _on_term(signum, frame):
+        abort()
+        prev = state.old_sigterm
+        if callable(prev):
+            prev(signum, frame)
+        else:
+            signal.signal(signal.SIGTERM, signal.SIG_DFL)
+            os.kill(os.getpid(), signal.SIGTERM)
+
+    try:
+        state.old_sigterm = signal.signal(signal.SIGTERM, _on_term)
+    except ValueError:
+        state.old_sigterm = None
+        return
+    try:
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        state.wakeup_prev_fd = signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+        state.wakeup_pipe = (r, w)
+    except (ValueError, OSError):
+        return
+    grace_s = float(os.environ.get("DIST_SIGTERM_GRACE_S", "1.0"))
+
+    def watch():
+        while True:
+            try:
+                data = os.read(r, 64)
+            except OSError:
+                return
+            if not data:
+                return
+            if signal.SIGTERM in data:
+                time.sleep(grace_s)
+                # still here: the main thread is inside a native call and the Python handler cannot run
+                abort()
+                os._exit(128 + int(signal.SIGTERM))
+
+    t = threading.Thread(target=watch, name="dist-sigterm-watch", daemon=True)
+    t.start()
+
+
+def _remove_sigterm_abort(st: "_State") -> None:
+    if st.old_sigterm is not None:
         try:
-            state.old_sigterm = signal.signal(signal.SIGTERM, _on_term)
+            signal.signal(signal.SIGTERM, st.old_sigterm)
         except ValueError:
-            state.old_sigterm = None
+            pass
+    if st.wakeup_pipe is not None:
+        try:
+            signal.set_wakeup_fd(st.wakeup_prev_fd if st.wakeup_prev_fd is not None else -1)
+        except (ValueError, OSError):
+            pass
+        r, w = st.wakeup_pipe
+        st.wakeup_pipe = None
+        for fd in (w, r):   # closing the write end makes the watcher's read return b"" and the thread end
+            try:
+                os.close(fd)
+            except OSError:
+                pass
 
 
 def comm_stream_info() -> Optional[dict]:
@@ -389,11 +447,7 @@ def destroy_process_group() -> None:
             st.monitor_stop.set()
         if st.heartbeat is not None:
             st.heartbeat.close()
-        if st.old_sigterm is not None:
-            try:
-                signal.signal(signal.SIGTERM, st.old_sigterm)
-            except ValueError:
-                pass
+        _remove_sigterm_abort(st)
         if st.comm is not None:
             st.comm.destroy()
         if st.owns_c10d and tdist.is_initialized():

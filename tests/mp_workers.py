@@ -381,3 +381,64 @@ def sharded_optimizer_worker(rank, world_size, out_dir):
     res["in_sync"] = shard.check_replicas_in_sync()
     _dump(out_dir, rank, res)
     dist.cleanup()
+
+
+def ddp_surface_worker(rank, world_size, out_dir):
+    """torch-DDP keyword / method surface of the wrapper: warned keywords, communication hooks, join(), and the
+    bit-pattern replica check (which must see a divergence that a plain sum of the parameters cannot)."""
+    import warnings
+
+    import distributed as dist
+
+    dist.init_process_group(rank, world_size, "gloo")
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(16, 32), nn.ReLU(), nn.Linear(32, 4))
+    res = {}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ddp = dist.prepare_ddp_model(model, device_ids=None, static_graph=True, mixed_precision=object(), output_device=None)
+        res["warned"] = sorted({str(x.message).split("(")[1].split("=")[0] for x in w if "has no effect" in str(x.message)})
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(rank)
+
+    def step():
+        x = torch.randn(8, 16, generator=g)
+        y = torch.randint(0, 4, (8,), generator=g)
+        opt.zero_grad()
+        nn.functional.cross_entropy(ddp(x), y).backward()
+        opt.step()
+
+    with ddp.join():
+        for _ in range(2):
+            step()
+    res["in_sync_after_training"] = ddp.check_replicas_in_sync()
+    # compressed all-reduce: buckets switch to fp16, training goes on, replicas stay identical
+    ddp.register_comm_hook(None, "fp16_compress")
+    res["bucket_dtype_after_hook"] = str(ddp.grad_arenas()[0].dtype)
+    step()
+    res["in_sync_after_compressed_step"] = ddp.check_replicas_in_sync()
+    ddp.register_comm_hook(None, "allreduce")
+    res["bucket_dtype_restored"] = str(ddp.grad_arenas()[0].dtype)
+    try:
+        ddp.register_comm_hook(None, lambda state, bucket: None)
+        res["custom_hook"] = None
+    except NotImplementedError as e:
+        res["custom_hook"] = str(e)[:40]
+    # two errors on rank 1 that cancel in a plain sum: the checksum sees nothing, the hashes do
+    if rank == 1:
+        with torch.no_grad():
+            wgt = ddp.module[0].weight
+            wgt[0, 0] += 0.5
+            wgt[0, 1] -= 0.5
+    res["checksum_says_in_sync"] = ddp.check_replicas_in_sync(rtol=1e-12)
+    res["hashes_say_in_sync"] = ddp.check_replicas_in_sync()
+    res["diverged"] = ddp.diverged_parameters()
+    # join(): a rank that runs fewer synchronised passes is reported instead of hanging its peers
+    try:
+        with ddp.join():
+            pass
+        res["join_even"] = True
+    except RuntimeError:
+        res["join_even"] = False
+    _dump(out_dir, rank, res)
+    dist.cleanup()

@@ -644,3 +644,43 @@ def test_weight_gradients_land_in_the_bucket_and_optimizer_waits_per_bucket(rccl
     assert not ddp.reducer.waits_pending()
     total = torch.stack([p.grad.float().norm() for p in ddp.parameters()]).sum().item()
     assert total == total and total > 0
+
+
+def test_sigterm_reaches_a_rank_that_is_blocked_in_a_native_wait(tmp_path):
+    """A rank sitting inside torch.cuda.synchronize() behind seconds of queued GPU work cannot run a Python signal
+    handler; SIGTERM must still abort its communicator and end it within the grace period (foreign launchers and
+    schedulers send SIGTERM and expect the process gone)."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    script = tmp_path / "blocked_rank.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "from distributed_pytorch_amd.parallel import process_group as pg\n"
+        "from distributed_pytorch_amd.parallel.store import Store\n"
+        "pg.init_process_group(0, 1, 'rccl', store=Store('127.0.0.1', 0, is_host=True, bind_addr='127.0.0.1'))\n"
+        "x = torch.zeros(8, device='cuda')\n"
+        "for _ in range(12):\n"
+        "    torch.cuda._sleep(2_000_000_000)\n"      # about a second of GPU time each
+        "print('blocked', flush=True)\n"
+        "torch.cuda.synchronize()\n"
+        "print('woke up by itself', flush=True)\n")
+    proc = subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                            env=dict(os.environ, DIST_QUIET_INIT="1"))
+    assert proc.stdout.readline().strip() == "blocked"
+    time.sleep(0.5)
+    t0 = time.time()
+    proc.send_signal(signal.SIGTERM)
+    try:
+        rc = proc.wait(timeout=8)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    took = time.time() - t0
+    assert rc in (-signal.SIGTERM, 128 + signal.SIGTERM), (rc, proc.stderr.read()[-2000:])
+    assert took < 6.0, took

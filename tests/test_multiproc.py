@@ -340,3 +340,15 @@ def test_sharded_optimizer_matches_full_optimizer(tmp_path, world):
         assert r["cons_keys_equal"] and r["cons_state_diff"] == 0.0 and r["cons_groups_equal"]
         assert r["lr_restored"] == [5e-3, 5e-3]
     assert sum(r["owned"] for r in rs) == 6
+
+
+def test_ddp_keyword_and_method_surface_world2(tmp_path):
+    dist.launch(mp_workers.ddp_surface_worker, str(tmp_path), nprocs=2)
+    for r in _read(tmp_path, 2):
+        assert r["warned"] == ["mixed_precision", "static_graph"] or r["warned"] == [], r["warned"]  # warned once per process
+        assert r["in_sync_after_training"] and r["in_sync_after_compressed_step"]
+        assert r["bucket_dtype_after_hook"] == "torch.float16" and r["bucket_dtype_restored"] == "torch.float32"
+        assert r["custom_hook"] and "register_comm_hook" in r["custom_hook"]
+        assert r["hashes_say_in_sync"] is False and r["diverged"] == ["0.weight"]
+        assert r["join_even"] is True
+    assert _read(tmp_path, 2)[0]["warned"] == ["mixed_precision", "static_graph"]

@@ -63,7 +63,7 @@ PYBIND11_MODULE(_C, m) {
       .def("group_end", &RcclComm::group_end)
       .def("num_async_ops", &RcclComm::num_async_ops)
       .def("destroy", &RcclComm::destroy, py::call_guard<py::gil_scoped_release>())
-      .def("abort", &RcclComm::abort)
+      .def("abort", &RcclComm::abort, py::call_guard<py::gil_scoped_release>())
       .def("set_debug_sync", &RcclComm::set_debug_sync, py::arg("on"))
       .def("debug_sync", &RcclComm::debug_sync)
       .def("comm_stream_idle", &RcclComm::comm_stream_idle)

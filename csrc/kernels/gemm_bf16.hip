@@ -47,6 +47,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // first): register e of lane l then holds C[row = m_base + (l&15)][col = n_base + 4*(l>>4) + e],
 // i.e. four consecutive output columns, which leave the lane as ONE 8-byte store instead of four
 // scattered 2-byte stores.
+template <typename TR = BF16>
 __device__ __forceinline__ void store_tile_bf16(const GemmArgs& p, const f32x4& acc, long long row, long long col0) {
   if (row >= p.M || col0 >= p.N) return;
   u16* C = static_cast<u16*>(p.C);
@@ -60,30 +61,30 @@ __device__ __forceinline__ void store_tile_bf16(const GemmArgs& p, const f32x4& 
     if (bias) {
       const u16x4 b = *reinterpret_cast<const u16x4*>(bias + col0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += BF16::to_f32(b[e]);
+      for (int e = 0; e < 4; ++e) v[e] += TR::to_f32(b[e]);
     }
     u16* cp = C + row * p.ldc + col0;
     if (p.beta != 0.f) {
       const u16x4 old = *reinterpret_cast<const u16x4*>(cp);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += p.beta * BF16::to_f32(old[e]);
+      for (int e = 0; e < 4; ++e) v[e] += p.beta * TR::to_f32(old[e]);
     }
     if (P) {
       u16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(v[e]);
+      for (int e = 0; e < 4; ++e) o[e] = TR::from_f32(v[e]);
       *reinterpret_cast<u16x4*>(P + row * p.ldc + col0) = o;
     }
     u16x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(act_fn(BF16::to_f32(BF16::from_f32(v[e])), p.act));  // activation of the value as stored
+    for (int e = 0; e < 4; ++e) o[e] = TR::from_f32(act_fn(TR::to_f32(TR::from_f32(v[e])), p.act));  // activation of the value as stored
     *reinterpret_cast<u16x4*>(cp) = o;
   } else {
     for (int e = 0; e < 4 && col0 + e < p.N; ++e) {
-      float x = v[e] + (bias ? BF16::to_f32(bias[col0 + e]) : 0.f);
-      if (p.beta != 0.f) x += p.beta * BF16::to_f32(C[row * p.ldc + col0 + e]);
-      if (P) P[row * p.ldc + col0 + e] = BF16::from_f32(x);
-      C[row * p.ldc + col0 + e] = BF16::from_f32(act_fn(BF16::to_f32(BF16::from_f32(x)), p.act));
+      float x = v[e] + (bias ? TR::to_f32(bias[col0 + e]) : 0.f);
+      if (p.beta != 0.f) x += p.beta * TR::to_f32(C[row * p.ldc + col0 + e]);
+      if (P) P[row * p.ldc + col0 + e] = TR::from_f32(x);
+      C[row * p.ldc + col0 + e] = TR::from_f32(act_fn(TR::to_f32(TR::from_f32(x)), p.act));
     }
   }
 }
@@ -93,7 +94,11 @@ __device__ __forceinline__ int kmajor_off(int row, int c) { return row * 128 + (
 // Byte offset of 16-byte chunk c (8 rows) of contraction index k in the swizzled [64][128] image.
 __device__ __forceinline__ int rmajor_off(int k, int c) { return k * 256 + ((c ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)))) << 4); }
 
-template <bool KMAJOR>
+// ALIGNED: every 8-element piece is either wholly inside the matrix and 16-byte aligned or wholly outside (base
+// address, leading dimension and contiguous extent are multiples of 8 elements): one 16-byte load per piece.
+// Otherwise (odd extents, leading dimensions or base addresses) the piece is gathered element by element with a
+// bounds check each -- the tail path that lets every shape run here; it costs load instructions, not correctness.
+template <bool KMAJOR, bool ALIGNED>
 __device__ __forceinline__ void load_tile(const u16* __restrict__ base, long long ld, long long r0, long long R, long long k0,
                                           long long K, u32x4 (&regs)[4]) {
 #pragma unroll
@@ -102,10 +107,30 @@ __device__ __forceinline__ void load_tile(const u16* __restrict__ base, long lon
     u32x4 v = {0u, 0u, 0u, 0u};
     if (KMAJOR) {
       const long long row = r0 + (id >> 3), k = k0 + ((id & 7) << 3);
-      if (row < R && k < K) v = *reinterpret_cast<const u32x4*>(base + row * ld + k);
+      if (ALIGNED) {
+        if (row < R && k < K) v = *reinterpret_cast<const u32x4*>(base + row * ld + k);
+      } else if (row < R && k < K) {
+        const u16* src = base + row * ld + k;
+        const int n = K - k < 8 ? static_cast<int>(K - k) : 8;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = j < n ? src[j] : static_cast<unsigned short>(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = static_cast<unsigned>(e[2 * j]) | (static_cast<unsigned>(e[2 * j + 1]) << 16);
+      }
     } else {
       const long long k = k0 + (id >> 4), row = r0 + ((id & 15) << 3);
-      if (k < K && row < R) v = *reinterpret_cast<const u32x4*>(base + k * ld + row);
+      if (ALIGNED) {
+        if (k < K && row < R) v = *reinterpret_cast<const u32x4*>(base + k * ld + row);
+      } else if (k < K && row < R) {
+        const u16* src = base + k * ld + row;
+        const int n = R - row < 8 ? static_cast<int>(R - row) : 8;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = j < n ? src[j] : static_cast<unsigned short>(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = static_cast<unsigned>(e[2 * j]) | (static_cast<unsigned>(e[2 * j + 1]) << 16);
+      }
     }
     regs[i] = v;
   }
@@ -141,7 +166,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int tile_row0, int 
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+// TR = BF16 or F16: the two 16-bit types share everything but the MFMA opcode and the epilogue's conversions.
+template <bool A_KMAJOR, bool B_KMAJOR, bool ALIGNED, typename TR>
 __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem_bf16[];
 
@@ -165,8 +191,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
 
   u32x4 ra[4], rb[4];
   const long long nk = (p.K + BK - 1) / BK;
-  load_tile<A_KMAJOR>(A, p.lda, m0, p.M, 0, p.K, ra);
-  load_tile<B_KMAJOR>(B, p.ldb, n0, p.N, 0, p.K, rb);
+  load_tile<A_KMAJOR, ALIGNED>(A, p.lda, m0, p.M, 0, p.K, ra);
+  load_tile<B_KMAJOR, ALIGNED>(B, p.ldb, n0, p.N, 0, p.K, rb);
   store_tile<A_KMAJOR>(smem_bf16, ra);
   store_tile<B_KMAJOR>(smem_bf16 + kTileBytes, rb);
   __syncthreads();
@@ -175,8 +201,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
   for (long long kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<A_KMAJOR>(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, ra);
-      load_tile<B_KMAJOR>(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, rb);
+      load_tile<A_KMAJOR, ALIGNED>(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, ra);
+      load_tile<B_KMAJOR, ALIGNED>(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, rb);
     }
     const char* as = smem_bf16 + cur * 2 * kTileBytes;
     const char* bs = as + kTileBytes;
@@ -190,7 +216,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (std::is_same<TR, F16>::value) {
+            typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          }
+        }
     }
     if (more) {
       char* an = smem_bf16 + (cur ^ 1) * 2 * kTileBytes;
@@ -206,7 +239,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      store_tile_bf16(p, acc[i][j], m0 + wm + 16 * i + (lane & 15), n0 + wn + 16 * j + 4 * (lane >> 4));
+      store_tile_bf16<TR>(p, acc[i][j], m0 + wm + 16 * i + (lane & 15), n0 + wn + 16 * j + 4 * (lane >> 4));
 }
 
 // =====================================================================================
@@ -965,26 +998,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
   store_tile_bf16(p, acc, row, col0);
 }
 
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// 16-byte global loads everywhere: contiguous extents, leading dimensions and base addresses in multiples of 8
+// elements.  The LDS-DMA kernel and split-K need this; the 128x128 kernel has an element-wise tail path for the rest.
+bool gemm_bf16_vector_aligned(const GemmArgs& a) {
+  if (a.lda % 8 || a.ldb % 8) return false;
+  if (a.a_kmajor ? (a.K % 8) : (a.M % 8)) return false;
+  if (a.b_kmajor ? (a.K % 8) : (a.N % 8)) return false;
+  if (a.A && !aligned16(a.A)) return false;
+  if (a.B && !aligned16(a.B)) return false;
+  return true;
+}
+
 bool use_large_tile(const GemmArgs& a) {
-  if (a.K % BK2 != 0) return false;
+  if (a.K % BK2 != 0 || !gemm_bf16_vector_aligned(a)) return false;
   if (a.M < 8 || a.N < 8) return false;
   // enough 256x256 tiles to occupy the chip, otherwise the 128x128 kernel spreads better
   const long long tiles = ((a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
   return tiles >= 128;
 }
 
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 }  // namespace
 
 bool gemm_bf16_act_backward_supported(const GemmArgs& a) {
-  return gemm_bf16_supported(a) && a.M % BM2 == 0 && a.N % BN2 == 0 && a.K % BK2 == 0 && (a.ldc & 7) == 0 && a.bias == nullptr &&
+  return gemm_bf16_supported(a) && gemm_bf16_vector_aligned(a) && a.M % BM2 == 0 && a.N % BN2 == 0 && a.K % BK2 == 0 && (a.ldc & 7) == 0 && a.bias == nullptr &&
          a.pre_act == nullptr && a.beta == 0.f && a.alpha == 1.f && a.act == kActNone && aligned16(a.C) && aligned16(a.aux) &&
          (a.aux_mode == kActGelu || a.aux_mode == kActRelu);
 }
 
 int gemm_bf16_split_k(const GemmArgs& a) {
-  if (!gemm_bf16_supported(a)) return 1;
+  if (!gemm_bf16_supported(a) || !gemm_bf16_vector_aligned(a)) return 1;
   if (a.K % BK2 != 0 || a.N % 4 != 0 || a.M < 8 || a.N < 8) return 1;
   const long long tiles = ((a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
   const long long nk = a.K / BK2;
@@ -1018,13 +1062,7 @@ int gemm_bf16_split_k(const GemmArgs& a) {
 
 bool gemm_bf16_supported(const GemmArgs& a) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
-  // 16-byte global loads: contiguous extents and leading dimensions in multiples of 8 elements.
-  if (a.lda % 8 || a.ldb % 8) return false;
   if (a.lda >= (1ll << 22) || a.ldb >= (1ll << 22)) return false;  // tile-relative byte offsets are 32-bit
-  if (a.a_kmajor ? (a.K % 8) : (a.M % 8)) return false;
-  if (a.b_kmajor ? (a.K % 8) : (a.N % 8)) return false;
-  if (a.A && !aligned16(a.A)) return false;
-  if (a.B && !aligned16(a.B)) return false;
   const long long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   return tiles < (1ll << 31);
 }
@@ -1107,9 +1145,30 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   const int tiles_m = static_cast<int>((a.M + BM - 1) / BM), tiles_n = static_cast<int>((a.N + BN - 1) / BN);
   const dim3 grid(static_cast<unsigned>(tiles_m) * static_cast<unsigned>(tiles_n));
   const size_t lds = 4 * kTileBytes;
+  const bool vec = gemm_bf16_vector_aligned(a);
   auto go = [&](auto ak, auto bk) {
     constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
-    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
+    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, true, BF16>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, false, BF16>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
+  };
+  if (a.a_kmajor && a.b_kmajor) go(std::true_type{}, std::true_type{});
+  else if (a.a_kmajor && !a.b_kmajor) go(std::true_type{}, std::false_type{});
+  else if (!a.a_kmajor && a.b_kmajor) go(std::false_type{}, std::true_type{});
+  else go(std::false_type{}, std::false_type{});
+}
+
+// fp16 products: the 128x128 kernel with the fp16 MFMA (the LDS-DMA kernel and split-K are bf16 only).
+bool gemm_f16_supported(const GemmArgs& a) { return gemm_bf16_supported(a) && a.aux_mode == kActNone; }
+
+void launch_gemm_f16(const GemmArgs& a, hipStream_t stream) {
+  const int tiles_m = static_cast<int>((a.M + BM - 1) / BM), tiles_n = static_cast<int>((a.N + BN - 1) / BN);
+  const dim3 grid(static_cast<unsigned>(tiles_m) * static_cast<unsigned>(tiles_n));
+  const size_t lds = 4 * kTileBytes;
+  const bool vec = gemm_bf16_vector_aligned(a);
+  auto go = [&](auto ak, auto bk) {
+    constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
+    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, true, F16>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, false, F16>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
   };
   if (a.a_kmajor && a.b_kmajor) go(std::true_type{}, std::true_type{});
   else if (a.a_kmajor && !a.b_kmajor) go(std::true_type{}, std::false_type{});

@@ -44,7 +44,10 @@ __device__ __forceinline__ int kmajor_off(int row, int c) { return row * BK + ((
 // Loads this thread's four 16-byte pieces of one operand tile into registers.
 //   KMAJOR : tile is rows [r0, r0+128) x k [k0, k0+32) of a [R][ld] matrix (k contiguous)
 //   !KMAJOR: tile is k [k0, k0+32) x rows [r0, r0+128) of a [K][ld] matrix (rows contiguous)
-template <bool KMAJOR>
+// ALIGNED: base address, leading dimension and contiguous extent are multiples of 4 floats, so a 4-float piece is
+// one aligned 16-byte load or wholly outside the matrix.  Otherwise the piece is gathered float by float with a
+// bounds check each (the tail path for odd shapes).
+template <bool KMAJOR, bool ALIGNED>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, long long ld, long long r0, long long R, long long k0,
                                           long long K, f32x4 (&regs)[4]) {
 #pragma unroll
@@ -53,10 +56,22 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long l
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (KMAJOR) {
       const long long row = r0 + (id >> 3), k = k0 + ((id & 7) << 2);
-      if (row < R && k < K) v = *reinterpret_cast<const f32x4*>(base + row * ld + k);
+      if (ALIGNED) {
+        if (row < R && k < K) v = *reinterpret_cast<const f32x4*>(base + row * ld + k);
+      } else if (row < R) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k + j < K) v[j] = base[row * ld + k + j];
+      }
     } else {
       const long long k = k0 + (id >> 5), row = r0 + ((id & 31) << 2);
-      if (k < K && row < R) v = *reinterpret_cast<const f32x4*>(base + k * ld + row);
+      if (ALIGNED) {
+        if (k < K && row < R) v = *reinterpret_cast<const f32x4*>(base + k * ld + row);
+      } else if (k < K) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (row + j < R) v[j] = base[k * ld + row + j];
+      }
     }
     regs[i] = v;
   }
@@ -86,7 +101,7 @@ __device__ __forceinline__ f32x4 read_frag(const float* lds, int tile_row0, int 
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, bool ALIGNED>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -113,8 +128,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs p, int t
 
   f32x4 ra[4], rb[4];
   const long long nk = (p.K + BK - 1) / BK;
-  load_tile<A_KMAJOR>(A, p.lda, m0, p.M, 0, p.K, ra);
-  load_tile<B_KMAJOR>(B, p.ldb, n0, p.N, 0, p.K, rb);
+  load_tile<A_KMAJOR, ALIGNED>(A, p.lda, m0, p.M, 0, p.K, ra);
+  load_tile<B_KMAJOR, ALIGNED>(B, p.ldb, n0, p.N, 0, p.K, rb);
   store_tile<A_KMAJOR>(smem, ra);
   store_tile<B_KMAJOR>(smem + kTileFloats, rb);
   __syncthreads();
@@ -123,8 +138,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs p, int t
   for (long long kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<A_KMAJOR>(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, ra);
-      load_tile<B_KMAJOR>(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, rb);
+      load_tile<A_KMAJOR, ALIGNED>(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, ra);
+      load_tile<B_KMAJOR, ALIGNED>(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, rb);
     }
     const float* as = smem + cur * 2 * kTileFloats;
     const float* bs = as + kTileFloats;
@@ -181,15 +196,21 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
-bool gemm_f32_supported(const GemmArgs& a) {
-  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
-  // 16-byte global loads: the contiguous dimension of each operand must be a multiple of 4
-  // floats, and so must its leading dimension and base address.
+namespace {
+// 16-byte global loads: the contiguous dimension of each operand, its leading dimension and its base address
+// are multiples of 4 floats.
+bool vector_aligned(const GemmArgs& a) {
   if (a.lda % 4 || a.ldb % 4) return false;
   if (a.a_kmajor ? (a.K % 4) : (a.M % 4)) return false;
   if (a.b_kmajor ? (a.K % 4) : (a.N % 4)) return false;
   if (a.A && !aligned16(a.A)) return false;
   if (a.B && !aligned16(a.B)) return false;
+  return true;
+}
+}  // namespace
+
+bool gemm_f32_supported(const GemmArgs& a) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
   const long long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   return tiles < (1ll << 31);
 }
@@ -198,9 +219,11 @@ void launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
   const int tiles_m = static_cast<int>((a.M + BM - 1) / BM), tiles_n = static_cast<int>((a.N + BN - 1) / BN);
   const dim3 grid(static_cast<unsigned>(tiles_m) * static_cast<unsigned>(tiles_n));
   const size_t lds = 4 * kTileFloats * sizeof(float);
+  const bool vec = vector_aligned(a);
   auto go = [&](auto ak, auto bk) {
     constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, true>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, false>), grid, dim3(kThreads), lds, stream, a, tiles_m, tiles_n);
   };
   if (a.a_kmajor && a.b_kmajor) go(std::true_type{}, std::true_type{});
   else if (a.a_kmajor && !a.b_kmajor) go(std::true_type{}, std::false_type{});

@@ -138,6 +138,9 @@ bool gemm_f32_supported(const GemmArgs& a);
 void launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 bool gemm_bf16_supported(const GemmArgs& a);
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
+// fp16 storage (fp32 accumulate) on the 128x128 MFMA kernel; same argument conventions.
+bool gemm_f16_supported(const GemmArgs& a);
+void launch_gemm_f16(const GemmArgs& a, hipStream_t stream);
 
 // Degenerate shapes of the reference MLP (in_dim = 1, n_classes = 4), fp32 or bf16 storage:
 //   y[M,N] = act(x[M,1] * w[N,1]^T + b)                     (K = 1 outer product)

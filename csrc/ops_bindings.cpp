@@ -421,13 +421,18 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> batchnorm_backward(Tensor dy, Tensor 
 
 // ------------------------------------------------------------------ linear layers
 bool gemm_path_ok(const kernels::GemmArgs& a, int dt) {
-  return dt == kernels::kF32 ? kernels::gemm_f32_supported(a) : (dt == kernels::kBF16 ? kernels::gemm_bf16_supported(a) : false);
+  return dt == kernels::kF32 ? kernels::gemm_f32_supported(a)
+                             : (dt == kernels::kBF16 ? kernels::gemm_bf16_supported(a) : (dt == kernels::kF16 ? kernels::gemm_f16_supported(a) : false));
 }
 
 // `like` supplies the device for the split-K workspace (fp32 partials, caching allocator).
 void run_gemm(const kernels::GemmArgs& a, int dt, hipStream_t s, const Tensor& like) {
   if (dt == kernels::kF32) {
     kernels::launch_gemm_f32(a, s);
+    return;
+  }
+  if (dt == kernels::kF16) {
+    kernels::launch_gemm_f16(a, s);
     return;
   }
   const int split = kernels::gemm_bf16_split_k(a);

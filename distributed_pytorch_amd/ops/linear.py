@@ -44,8 +44,6 @@ def native_route(M: int, N: int, K: int, dtype: torch.dtype) -> str:
     name = {torch.float32: "float32", torch.bfloat16: "bfloat16", torch.float16: "float16"}.get(dtype)
     if name is None:
         return "unsupported"
-    if name == "float16" and K != 1 and N > 16:
-        return "unsupported"  # MFMA GEMMs are provided for float32 and bfloat16
     return _ext.C().linear_route(M, N, K, name)
 
 
@@ -131,13 +129,14 @@ def library_linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optiona
 
 
 def linear_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
-                    allow_library_gemm: bool = True) -> torch.Tensor:
+                    allow_library_gemm: bool = False) -> torch.Tensor:
     """``act(x @ weight.T + bias)`` for x of shape ``[..., K]``.
 
-    GPU tensors run on the native kernels.  A shape the MFMA GEMM cannot take (extents that
-    are not multiples of the 16-byte vector width) goes to the vendor GEMM through torch when
-    ``allow_library_gemm`` is set, and raises otherwise; there is no silent change of path
-    for supported shapes.
+    GPU tensors of float32 / bfloat16 / float16 run on the native kernels, whatever their extents
+    (odd sizes take the element-wise tail path of the 128x128 MFMA kernel).  What is left for
+    "unsupported" is a dtype outside those three, mixed x / weight dtypes or a leading dimension
+    beyond 4 Mi elements: that raises, unless ``allow_library_gemm`` asks for the vendor GEMM
+    behind torch instead.
     """
     code = _act_code(act)
     if not x.is_cuda:

@@ -392,8 +392,11 @@ def _install_sigterm_abort(state: "_State") -> None:
                 return
             if signal.SIGTERM in data:
                 time.sleep(grace_s)
-                # still here: the main thread is inside a native call and the Python handler cannot run
-                abort()
+                # still here: the main thread is inside a native call and the Python handler cannot run.  The abort
+                # itself may wait for the device (it drains the communicator's streams), so it gets a bounded time.
+                worker = threading.Thread(target=abort, name="dist-sigterm-abort", daemon=True)
+                worker.start()
+                worker.join(grace_s + 1.0)
                 os._exit(128 + int(signal.SIGTERM))
 
     t = threading.Thread(target=watch, name="dist-sigterm-watch", daemon=True)

@@ -293,6 +293,8 @@ def run_rank(rank: int, world_size: int, argv):
     if args.emulate_ranks > 1:
         result["emulated_allreduce_load"] = {"ranks": args.emulate_ranks, "busbw_gbps": args.emulate_busbw, "workgroups": args.emulate_wgs,
                                              "note": "one GPU; a stand-in kernel occupies the communication stream, no data crosses a link"}
+    if on_rccl and pg.get_comm().one_rank_identity():
+        result["config"]["one_rank_allreduce"] = "skipped (identity): reducer machinery only"
     if on_rccl:
         info_cs = pg.comm_stream_info() or {}
         result["config"]["comm_stream"] = {k: info_cs.get(k) for k in ("priority", "independent", "candidates_tried")}

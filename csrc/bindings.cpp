@@ -59,6 +59,8 @@ PYBIND11_MODULE(_C, m) {
       .def("set_emulation", &RcclComm::set_emulation, py::arg("ranks"), py::arg("busbw_gbps"), py::arg("workgroups") = 32,
            py::arg("passes") = 2, py::arg("latency_us") = 30.0)
       .def("emulating", &RcclComm::emulating)
+      .def("set_one_rank_identity", &RcclComm::set_one_rank_identity, py::arg("on"))
+      .def("one_rank_identity", &RcclComm::one_rank_identity)
       .def("group_start", &RcclComm::group_start)
       .def("group_end", &RcclComm::group_end)
       .def("num_async_ops", &RcclComm::num_async_ops)

@@ -320,7 +320,7 @@ void RcclComm::all_reduce_async(at::Tensor t, int op, int slot) {
     const double bytes = static_cast<double>(t.numel()) * static_cast<double>(t.element_size());
     const double ms = 2.0 * (emu_ranks_ - 1) / emu_ranks_ * bytes / (emu_busbw_gbps_ * 1e9) * 1e3 + emu_latency_us_ * 1e-3;
     kernels::launch_emulated_collective(t.data_ptr(), static_cast<long long>(bytes), emu_workgroups_, emu_passes_, ms, comm_stream_);
-  } else if (t.numel() > 0) {
+  } else if (t.numel() > 0 && !one_rank_identity_) {
     std::lock_guard<std::timed_mutex> lk(comm_mu_);
     if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
     DPA_NCCL_CHECK(ncclAllReduce(t.data_ptr(), t.data_ptr(), static_cast<size_t>(t.numel()), to_nccl_dtype(t.scalar_type()),

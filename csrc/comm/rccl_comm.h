@@ -99,6 +99,11 @@ class RcclComm {
   // moves the buffer `passes` times through HBM meanwhile.  Same fences, events and stream as the real path.
   void set_emulation(int ranks, double busbw_gbps, int workgroups, int passes, double latency_us);
   bool emulating() const { return emu_ranks_ > 1; }
+  // A one-rank all-reduce is the identity; the library still runs a kernel that copies the buffer over itself.
+  // With this on, the asynchronous all-reduces of a ONE-rank communicator skip the library call (fences and
+  // completion events stay), which isolates what the reducer machinery itself costs (DIST_ONE_RANK_IDENTITY=1).
+  void set_one_rank_identity(bool on) { one_rank_identity_ = on && world_ == 1; }
+  bool one_rank_identity() const { return one_rank_identity_; }
 
   // Overlap accounting.  While enabled, every asynchronous collective is bracketed by two
   // timing events on the communication stream and wait_all_slots() by two on the compute
@@ -129,6 +134,7 @@ class RcclComm {
   bool destroyed_ = false;
   bool debug_sync_ = false;
   bool timing_ = false;
+  bool one_rank_identity_ = false;
   int emu_ranks_ = 0, emu_workgroups_ = 32, emu_passes_ = 2;
   double emu_busbw_gbps_ = 0.0, emu_latency_us_ = 30.0;
   std::vector<hipEvent_t> timing_pool_;                       // timing-enabled events, reused

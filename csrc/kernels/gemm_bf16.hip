@@ -358,6 +358,50 @@ template <bool KMAJOR>
 __device__ __forceinline__ const char* dma_base(const u16* base, long long ld, long long r0, long long k0) {
   return reinterpret_cast<const char*>(KMAJOR ? base + r0 * ld + k0 : base + k0 * ld + r0);
 }
+// Implicit 3x3 convolution, operand A (conv_mode 1): tile-relative row -> output pixel (b, h, w) -> byte offset of
+// the haloed pixel (b, h, w) -- the top-left tap -- from X's origin, plus the lane's swizzled 16-byte chunk.  The
+// k-steps then walk (dh, dw, c) by moving the wave-uniform base only: 3*C consecutive elements per kernel row.
+__device__ __forceinline__ void dma_offsets_conv_a(const GemmArgs& p, long long r0, int wid, int lane, unsigned (&off)[2][2]) {
+  const long long room = p.M - r0 - 1;
+  const unsigned lim = static_cast<unsigned>(room < 255 ? room : 255);
+  const unsigned H = static_cast<unsigned>(p.conv_H), W = static_cast<unsigned>(p.conv_W), HW = H * W;
+  const unsigned pix_bytes = static_cast<unsigned>(p.conv_C) * 2u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wid * 2 + i;
+      const int lr = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+      unsigned rel = static_cast<unsigned>((lr / 64) * 128 + h * 64 + lr % 64);
+      rel = rel < lim ? rel : lim;
+      const unsigned m = static_cast<unsigned>(r0) + rel;  // M < 2^31 (checked by the host)
+      const unsigned b = m / HW, rem = m - b * HW, hh = rem / W, ww = rem - hh * W;
+      const unsigned pix = (b * (H + 2u) + hh) * (W + 2u) + ww;
+      off[h][i] = pix * pix_bytes + static_cast<unsigned>(c * 16);
+    }
+}
+// Operand B of the weight gradient (conv_mode 2): column n = (3*dh + dw)*C + c of the [K][N] operand lives at
+// X row (q + dh*(W+2) + dw - (W+3)), channel c; the "- (W+3)" is folded into the wave-uniform base.
+__device__ __forceinline__ void dma_offsets_conv_b(const GemmArgs& p, long long r0, int wid, int lane, unsigned (&off)[2][2]) {
+  const long long room = p.N - r0 - 8;
+  const unsigned lim = static_cast<unsigned>(room < 255 ? room : 255);
+  const unsigned C = static_cast<unsigned>(p.conv_C), W2 = static_cast<unsigned>(p.conv_W) + 2u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wid * 2 + i;
+      const int k = piece * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ (2 * ((k & 3) + 4 * ((k >> 3) & 1)));
+      const int lr = c * 8;
+      unsigned rel = static_cast<unsigned>((lr / 32) * 64 + h * 32 + lr % 32);
+      rel = rel < lim ? rel : lim;
+      const unsigned n = static_cast<unsigned>(r0) + rel;
+      const unsigned dh = n / (3u * C), within = n - dh * 3u * C;   // (dw, c) are contiguous in X
+      off[h][i] = (static_cast<unsigned>(k) * C + dh * W2 * C + within) * 2u;
+    }
+}
 // Issued as inline assembly: the compiler orders every LDS read it cannot prove disjoint from an
 // LDS-DMA it knows about (the transposing reads always) behind s_waitcnt vmcnt(0), which would put
 // the whole DMA of tile k+1 in front of the math of tile k.  The kernel orders DMA and reads itself
@@ -451,8 +495,12 @@ constexpr int kStreamingMaxKSteps = 64;  // beyond K = 4096 a tile is long enoug
 // the current one is finished, so that only the first tile of a workgroup pays the memory latency of a
 // cold start and the next tile's operands are in LDS when the epilogue ends.  Drawing ids instead of
 // fixing them per workgroup keeps the kernel balanced when another stream (a collective) holds some CUs.
-template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT>
+// CONV: 0 = plain product; 1 = operand A is the implicit 3x3-convolution view of a haloed image (NT layout);
+// 2 = operand B is that view for the weight gradient (split-K TN layout).  See GemmArgs::conv_mode.
+template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT, int CONV = 0>
 __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters, unsigned* tile_counter) {
+  static_assert(CONV == 0 || (CONV == 1 && A_KMAJOR && B_KMAJOR && !SPLIT) || (CONV == 2 && !A_KMAJOR && !B_KMAJOR && SPLIT),
+                "convolution views exist for the NT forward product and the split-K TN weight gradient");
   extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 k-steps][B0 | A0 | B1 | A1][GELU table][staging][control]
   DPA_STAMP(0);
   DPA_STAMP_REAL(4);
@@ -531,15 +579,32 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     // offsets to the top of the kernel and keep (spill) them across everything
     int l = lane;
     asm volatile("" : "+v"(l));
-    dma_offsets<A_KMAJOR, 64>(p.lda, rm0, p.M, wid, l, off_a);
-    dma_offsets<B_KMAJOR, 32>(p.ldb, rn0, p.N, wid, l, off_b);
+    if constexpr (CONV == 1) dma_offsets_conv_a(p, rm0, wid, l, off_a);
+    else dma_offsets<A_KMAJOR, 64>(p.lda, rm0, p.M, wid, l, off_a);
+    if constexpr (CONV == 2) dma_offsets_conv_b(p, rn0, wid, l, off_b);
+    else dma_offsets<B_KMAJOR, 32>(p.ldb, rn0, p.N, wid, l, off_b);
   };
+  // CONV == 1: the A base does not depend on the tile; it walks 128 bytes per k-step through the 3*C contiguous
+  // elements of a kernel row and jumps to the next image row every 3*C/64 k-steps.
+  const int conv_row_steps = CONV == 1 ? 3 * p.conv_C / BK2 : 0;
+  const long long conv_row_jump = CONV == 1 ? static_cast<long long>(p.conv_W - 1) * p.conv_C * 2 : 0;
+  int conv_step = 0;
   auto set_cursor = [&](int id) __attribute__((always_inline)) {
     long long rm0, rn0;
     tile_origin(id, rm0, rn0);
     set_offsets(id);
-    r_aptr = uniform_ptr(dma_base<A_KMAJOR>(A, p.lda, rm0, kt0 * BK2));
-    r_bptr = uniform_ptr(dma_base<B_KMAJOR>(B, p.ldb, rn0, kt0 * BK2));
+    if constexpr (CONV == 1) {
+      r_aptr = uniform_ptr(reinterpret_cast<const char*>(A));
+      conv_step = 0;
+    } else {
+      r_aptr = uniform_ptr(dma_base<A_KMAJOR>(A, p.lda, rm0, kt0 * BK2));
+    }
+    if constexpr (CONV == 2) {
+      // k-step kt0 of X, shifted up by the (W + 3) rows that dma_offsets_conv_b adds back per column
+      r_bptr = uniform_ptr(reinterpret_cast<const char*>(B + (kt0 * BK2 - (p.conv_W + 3)) * p.conv_C));
+    } else {
+      r_bptr = uniform_ptr(dma_base<B_KMAJOR>(B, p.ldb, rn0, kt0 * BK2));
+    }
   };
   // Requests the next half-tile of the stream; `which` runs B0 A0 B1 A1 B0 ... by construction of the callers.
   auto request = [&](auto which_c) __attribute__((always_inline)) {
@@ -548,7 +613,15 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     else dma_issue(r_bptr, off_b[which >> 1], r_dst + which * kHalfBytes);
     if (which == kHalfA1) {  // k-step complete
       r_dst ^= 2 * kTileBytes2;
-      r_aptr += a_step;
+      if constexpr (CONV == 1) {
+        r_aptr += BK2 * 2;
+        if (++conv_step == conv_row_steps) {
+          conv_step = 0;
+          r_aptr += conv_row_jump;
+        }
+      } else {
+        r_aptr += a_step;
+      }
       r_bptr += b_step;
     }
   };
@@ -1098,11 +1171,27 @@ bool use_streaming(const GemmArgs& a, long long tiles, bool split) {
   return s.counters != nullptr && s.cus > 0 && nk >= 3 && nk <= kStreamingMaxKSteps && tiles >= 3ll * s.cus;
 }
 
+bool gemm_bf16_conv_supported(const GemmArgs& a) {
+  if (a.conv_mode != 1 && a.conv_mode != 2) return false;
+  if (a.conv_B <= 0 || a.conv_H <= 0 || a.conv_W <= 0 || a.conv_C <= 0 || a.conv_C % BK2 != 0) return false;
+  const long long halo_pixels = static_cast<long long>(a.conv_B) * (a.conv_H + 2) * (a.conv_W + 2);
+  // per-lane byte offsets into the haloed image are 32-bit
+  if ((halo_pixels + 2ll * (a.conv_W + 3) + 64) * a.conv_C * 2 >= (1ll << 32)) return false;
+  if (a.bias != nullptr || a.pre_act != nullptr || a.aux_mode != kActNone || a.act != kActNone || a.beta != 0.f) return false;
+  if (!aligned16(a.A) || !aligned16(a.B)) return false;
+  if (a.conv_mode == 1) {
+    return a.a_kmajor && a.b_kmajor && a.M == static_cast<long long>(a.conv_B) * a.conv_H * a.conv_W && a.M < (1ll << 31) &&
+           a.K == 9ll * a.conv_C && a.ldb == a.K && a.N % 8 == 0 && a.N >= 8;
+  }
+  return !a.a_kmajor && !a.b_kmajor && a.N == 9ll * a.conv_C && a.ldb == a.conv_C && a.K % BK2 == 0 && a.K >= halo_pixels &&
+         a.M % 8 == 0 && a.M >= 8 && a.lda % 8 == 0 && a.workspace != nullptr && a.split_k >= 1;
+}
+
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
-  const bool split = a.split_k > 1 && a.workspace != nullptr;
+  const bool split = (a.split_k > 1 || a.conv_mode == 2) && a.workspace != nullptr;
   // the activation-backward epilogue exists in the large-tile kernel only (callers check
   // gemm_bf16_act_backward_supported first)
-  if (split || use_large_tile(a) || a.aux_mode != kActNone) {
+  if (split || use_large_tile(a) || a.aux_mode != kActNone || a.conv_mode != 0) {
     const int tm2 = static_cast<int>((a.M + BM2 - 1) / BM2), tn2 = static_cast<int>((a.N + BN2 - 1) / BN2);
     const long long nk = a.K / BK2;
     const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);
@@ -1115,7 +1204,27 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
       (void)hipMemsetAsync(counter, 0, 16, stream);
       grid_x = static_cast<unsigned>(s.cus);
     }
-    const dim3 grid2(grid_x, split ? static_cast<unsigned>(a.split_k) : 1u);
+    const dim3 grid2(grid_x, split ? static_cast<unsigned>(a.split_k > 1 ? a.split_k : 1) : 1u);
+    if (a.conv_mode != 0) {
+      static bool conv_configured = false;
+      if (!conv_configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<true, true, false, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<false, false, true, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes2);
+        conv_configured = true;
+      }
+      if (a.conv_mode == 1) {
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<true, true, false, 1>), grid2, dim3(kThreads2), kLdsBytes2, stream, a, tm2, tn2, k_iters,
+                           counter);
+      } else {
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<false, false, true, 2>), grid2, dim3(kThreads2), kLdsBytes2, stream, a, tm2, tn2, k_iters,
+                           counter);
+        const long long quads = a.M * (a.N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, stream, a);
+      }
+      return;
+    }
     // all of a CU's LDS but 960 bytes: above the 64 KiB default, so the limit is raised per kernel
     const size_t lds2 = kLdsBytes2;
     auto go2 = [&](auto ak, auto bk) {

@@ -129,6 +129,16 @@ struct GemmArgs {
   const void* aux;
   int aux_mode;
   float* colsum_partial;
+  // Implicit 3x3 convolution, stride 1, zero padding 1, over a channels-last image X that carries a one-pixel
+  // zero halo: X[conv_B][conv_H + 2][conv_W + 2][conv_C], conv_C % 64 == 0 (bf16, large-tile kernel only).
+  //   conv_mode 1 (forward / input gradient, NT layout): row m of A is output pixel (b, h, w) and its k index runs
+  //     over (dh, dw, c):  A[m][(3*dh + dw)*C + c] = X[b][h + dh][w + dw][c]  (dh, dw = 0..2 in halo coordinates).
+  //     A points to X[0][0][0][0]; M = B*H*W, K = 9*C; B is the weight as [N][9*C] (a channels-last [N, C, 3, 3]).
+  //   conv_mode 2 (weight gradient, split-K TN layout): the contraction runs over ALL haloed pixels q; A is the
+  //     haloed output gradient [Q][M] (zero halo), column n = (3*dh + dw)*C + c of B reads X row q + (dh-1)*(W+2) + (dw-1),
+  //     channel c.  B points to X row 0; (W + 3) rows before and after it must be readable zeros.  N = 9*C, ldb = C.
+  int conv_mode;
+  int conv_B, conv_H, conv_W, conv_C;
 };
 // Number of contraction ranges worth using for this product (1 = do not split): > 1 when the
 // output has too few 256x256 tiles to occupy the chip but a long contraction (weight gradients).
@@ -137,10 +147,17 @@ bool gemm_bf16_act_backward_supported(const GemmArgs& a);
 bool gemm_f32_supported(const GemmArgs& a);
 void launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 bool gemm_bf16_supported(const GemmArgs& a);
+// Argument check for the implicit-convolution views (GemmArgs::conv_mode 1 / 2); launch_gemm_bf16 runs them.
+bool gemm_bf16_conv_supported(const GemmArgs& a);
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
 // fp16 storage (fp32 accumulate) on the 128x128 MFMA kernel; same argument conventions.
 bool gemm_f16_supported(const GemmArgs& a);
 void launch_gemm_f16(const GemmArgs& a, hipStream_t stream);
+
+// dst [rows_total][C] (bf16, 16-byte aligned): row guard_front + q is haloed pixel q of x [B][H][W][C] -- zero on the
+// one-pixel frame of every image -- and every row outside [guard_front, guard_front + B*(H+2)*(W+2)) is zero.
+void launch_pad_halo(const void* x, void* dst, long long rows_total, long long guard_front, int B, int H, int W, int C,
+                     hipStream_t stream);
 
 // Degenerate shapes of the reference MLP (in_dim = 1, n_classes = 4), fp32 or bf16 storage:
 //   y[M,N] = act(x[M,1] * w[N,1]^T + b)                     (K = 1 outer product)

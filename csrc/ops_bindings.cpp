@@ -696,6 +696,90 @@ Tensor gemm(Tensor A, Tensor B, bool a_kmajor, bool b_kmajor, c10::optional<Tens
   return C;
 }
 
+// ------------------------------------------------------------------ 3x3 convolution (stride 1, padding 1) as an implicit GEMM
+namespace {
+struct HaloGeom {
+  int64_t B, H, W, C, guard, Q, Kpad, rows_total;
+};
+HaloGeom halo_geom(int64_t B, int64_t H, int64_t W, int64_t C) {
+  HaloGeom g{B, H, W, C, 0, 0, 0, 0};
+  g.guard = W + 3;
+  g.Q = B * (H + 2) * (W + 2);
+  g.Kpad = (g.Q + 63) / 64 * 64;
+  g.rows_total = g.guard + g.Kpad + g.guard;
+  return g;
+}
+}  // namespace
+
+// x: [B, H, W, C] contiguous bf16 (the channels-last image seen as rows).  Returns the zero-haloed copy
+// [guard + Kpad + guard, C]; haloed pixel q is row guard + q (see kernels::launch_pad_halo).
+Tensor conv3x3_pad(Tensor x) {
+  check_gpu(x, "x");
+  TORCH_CHECK(x.dim() == 4 && x.is_contiguous() && x.scalar_type() == at::kBFloat16, "conv3x3_pad: contiguous bf16 [B, H, W, C] expected");
+  const HaloGeom g = halo_geom(x.size(0), x.size(1), x.size(2), x.size(3));
+  TORCH_CHECK(g.C % 64 == 0, "conv3x3_pad: channels must be a multiple of 64");
+  Tensor buf = at::empty({g.rows_total, g.C}, x.options());
+  DevGuard guard(x);
+  kernels::launch_pad_halo(x.data_ptr(), buf.data_ptr(), g.rows_total, g.guard, static_cast<int>(g.B), static_cast<int>(g.H),
+                           static_cast<int>(g.W), static_cast<int>(g.C), stream_of(x));
+  return buf;
+}
+
+// y[B*H*W, N] = sum over taps of X[pixel + tap] . w[N][tap][C]   (xpad from conv3x3_pad, w: [N, 9*C] contiguous).
+Tensor conv3x3_forward(Tensor xpad, Tensor w, int64_t B, int64_t H, int64_t W) {
+  check_gpu(xpad, "xpad");
+  check_gpu(w, "weight");
+  TORCH_CHECK(xpad.dim() == 2 && w.dim() == 2 && xpad.is_contiguous() && w.is_contiguous(), "conv3x3_forward: 2-D contiguous tensors expected");
+  TORCH_CHECK(xpad.scalar_type() == at::kBFloat16 && w.scalar_type() == at::kBFloat16, "conv3x3_forward: bf16 expected");
+  const HaloGeom g = halo_geom(B, H, W, xpad.size(1));
+  TORCH_CHECK(xpad.size(0) == g.rows_total && w.size(1) == 9 * g.C, "conv3x3_forward: xpad / weight do not match the image geometry");
+  const int64_t N = w.size(0);
+  Tensor y = at::empty({B * H * W, N}, xpad.options());
+  kernels::GemmArgs a{};
+  a.A = static_cast<const char*>(xpad.data_ptr()) + g.guard * g.C * 2;
+  a.B = w.data_ptr();
+  a.C = y.data_ptr();
+  a.M = B * H * W; a.N = N; a.K = 9 * g.C; a.lda = a.K; a.ldb = a.K; a.ldc = N;
+  a.a_kmajor = 1; a.b_kmajor = 1; a.alpha = 1.f;
+  a.conv_mode = 1; a.conv_B = static_cast<int>(B); a.conv_H = static_cast<int>(H); a.conv_W = static_cast<int>(W); a.conv_C = static_cast<int>(g.C);
+  TORCH_CHECK(kernels::gemm_bf16_conv_supported(a), "conv3x3_forward: unsupported geometry B=", B, " H=", H, " W=", W, " C=", g.C, " N=", N);
+  DevGuard guard(xpad);
+  kernels::launch_gemm_bf16(a, stream_of(xpad));
+  return y;
+}
+
+// dW[Cout, 9*Cin] = sum over all haloed pixels q of dY[q][Cout]^T X[q + tap][Cin]   (both from conv3x3_pad of the same geometry).
+Tensor conv3x3_wgrad(Tensor dypad, Tensor xpad, int64_t B, int64_t H, int64_t W) {
+  check_gpu(dypad, "dypad");
+  check_gpu(xpad, "xpad");
+  TORCH_CHECK(dypad.dim() == 2 && xpad.dim() == 2 && dypad.is_contiguous() && xpad.is_contiguous(), "conv3x3_wgrad: 2-D contiguous tensors expected");
+  TORCH_CHECK(dypad.scalar_type() == at::kBFloat16 && xpad.scalar_type() == at::kBFloat16, "conv3x3_wgrad: bf16 expected");
+  const HaloGeom g = halo_geom(B, H, W, xpad.size(1));
+  const int64_t Cout = dypad.size(1);
+  TORCH_CHECK(xpad.size(0) == g.rows_total && dypad.size(0) == g.rows_total, "conv3x3_wgrad: operands do not match the image geometry");
+  Tensor dw = at::empty({Cout, 9 * g.C}, xpad.options());
+  kernels::GemmArgs a{};
+  a.A = static_cast<const char*>(dypad.data_ptr()) + g.guard * Cout * 2;
+  a.B = static_cast<const char*>(xpad.data_ptr()) + g.guard * g.C * 2;
+  a.C = dw.data_ptr();
+  a.M = Cout; a.N = 9 * g.C; a.K = g.Kpad; a.lda = Cout; a.ldb = g.C; a.ldc = a.N;
+  a.a_kmajor = 0; a.b_kmajor = 0; a.alpha = 1.f;
+  a.conv_mode = 2; a.conv_B = static_cast<int>(B); a.conv_H = static_cast<int>(H); a.conv_W = static_cast<int>(W); a.conv_C = static_cast<int>(g.C);
+  // one wave of workgroups over the chip: tiles * ranges ~ 256, at least 16 k-steps per range
+  const int64_t tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256), nk = a.K / 64;
+  int64_t split = std::max<int64_t>(1, 256 / tiles);
+  split = std::min<int64_t>(split, std::max<int64_t>(1, nk / 16));
+  const int64_t iters = (nk + split - 1) / split;
+  split = (nk + iters - 1) / iters;
+  Tensor ws = at::empty({split * a.M * a.N}, xpad.options().dtype(at::kFloat));
+  a.workspace = ws.data_ptr<float>();
+  a.split_k = static_cast<int>(split);
+  TORCH_CHECK(kernels::gemm_bf16_conv_supported(a), "conv3x3_wgrad: unsupported geometry B=", B, " H=", H, " W=", W, " Cin=", g.C, " Cout=", Cout);
+  DevGuard guard(xpad);
+  kernels::launch_gemm_bf16(a, stream_of(xpad));
+  return dw;
+}
+
 // g = (dout @ w) * act'(aux) in one kernel, plus db = colsum(g) when wanted: the input-gradient
 // GEMM of a layer fused with the activation backward of the layer in front of it.
 //   dout [M, K] (gradient of the layer's output), w [K, N] (its weight, as stored: [out, in]),
@@ -943,6 +1027,9 @@ void init_ops(py::module_& m) {
   m.def("rank1_mlp_backward", &rank1_mlp_backward, py::arg("dy"), py::arg("x"), py::arg("w1"), py::arg("b1"), py::arg("W2"), py::arg("act") = 0);
   m.def("act_backward", &act_backward, py::arg("dy"), py::arg("saved"), py::arg("act"), py::arg("need_db") = false);
   m.def("colsum", &colsum);
+  m.def("conv3x3_pad", &conv3x3_pad, py::arg("x_nhwc"));
+  m.def("conv3x3_forward", &conv3x3_forward, py::arg("xpad"), py::arg("weight"), py::arg("B"), py::arg("H"), py::arg("W"));
+  m.def("conv3x3_wgrad", &conv3x3_wgrad, py::arg("dypad"), py::arg("xpad"), py::arg("B"), py::arg("H"), py::arg("W"));
   m.def("gemm", &gemm, py::arg("A"), py::arg("B"), py::arg("a_kmajor") = true, py::arg("b_kmajor") = true, py::arg("bias") = py::none(),
         py::arg("act") = 0, py::arg("out") = py::none());
   m.def("batchnorm_supported", [](int64_t R, int64_t C, const std::string& dtype) {

@@ -1,7 +1,8 @@
 """ResNet-50 (bottleneck v1.5: stride on the 3x3 convolution), defined from scratch for the
-"ResNet-50, synthetic 224 x 224, bf16" data-parallel configuration.  The 3x3 / 7x7 / strided
-convolutions run on the vendor library through torch (MIOpen) in channels-last layout; the 1x1
-stride-1 convolutions (a GEMM over channels-last rows), batch norm (with the ReLU and
+"ResNet-50, synthetic 224 x 224, bf16" data-parallel configuration.  The 7x7 stem, the strided
+and the narrow (64 / 128 channel) 3x3 convolutions run on the vendor library through torch (MIOpen)
+in channels-last layout; the 1x1 stride-1 convolutions (a GEMM over channels-last rows), the 3x3
+stride-1 convolutions of stages 3 and 4 (implicit GEMMs, ops/conv.py), batch norm (with the ReLU and
 the residual add of a block folded into it), the classifier head, the loss (fused softmax
 cross-entropy + accuracy), the optimizer and the gradient reducer are this framework's
 kernels.  BatchNorm running statistics are module buffers, which the DDP wrapper keeps in one
@@ -13,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ..ops.batchnorm import BatchNorm2d
-from ..ops.conv import PointwiseConv2d
+from ..ops.conv import Conv3x3, PointwiseConv2d
 from ..ops.linear import Linear
 
 
@@ -24,7 +25,7 @@ class Bottleneck(nn.Module):
         super().__init__()
         self.conv1 = PointwiseConv2d(inplanes, planes)
         self.bn1 = BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.conv2 = Conv3x3(planes, planes, stride=stride)
         self.bn2 = BatchNorm2d(planes)
         self.conv3 = PointwiseConv2d(planes, planes * self.expansion)
         self.bn3 = BatchNorm2d(planes * self.expansion)

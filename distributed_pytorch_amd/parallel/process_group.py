@@ -302,6 +302,8 @@ def init_process_group(rank: int, world_size: int, backend: Optional[str] = None
         except RuntimeError as exc:
             raise RuntimeError(f"{exc}\n  " + _INIT_HINT % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>")) from exc
         state.comm.set_debug_sync(debug_sync())
+        if world_size == 1 and os.environ.get("DIST_ONE_RANK_IDENTITY", "0") == "1":
+            state.comm.set_one_rank_identity(True)   # measure the reducer machinery without the library's one-rank copy kernel
         # The communication stream is chosen here, once per process and device (csrc/comm/comm_stream.h): a stream of
         # normal priority -- or, with DIST_COMM_STREAM=high, of high priority -- that a bounded probe has seen run
         # concurrently with the compute stream.  Every later communicator of the process reuses it.

@@ -1056,3 +1056,42 @@ def test_token_position_embedding_fallback_and_range_check(monkeypatch):
     monkeypatch.setenv("DIST_CHECK_TARGETS", "1")
     with pytest.raises(IndexError):
         token_position_embedding(bad, wte, wpe)
+
+
+# ----------------------------------------------------------------------------- 3x3 convolution as implicit GEMM
+@pytest.mark.parametrize("B,C_in,C_out,H,W", [(2, 64, 64, 8, 8), (3, 64, 128, 7, 9), (4, 128, 64, 14, 14), (2, 256, 256, 5, 5),
+                                               (16, 64, 64, 56, 56), (8, 512, 512, 7, 7), (1, 128, 192, 1, 1), (5, 64, 320, 3, 17)])
+def test_conv3x3_implicit_gemm_matches_fp32_reference(B, C_in, C_out, H, W):
+    """Forward, input gradient and weight gradient of the implicit-GEMM 3x3 convolution against torch's convolution
+    in fp32 on the same bf16-rounded operands."""
+    from distributed_pytorch_amd.ops.conv import Conv3x3
+
+    torch.manual_seed(B + C_in + H)
+    conv = Conv3x3(C_in, C_out, min_channels=64).to(DEV).bfloat16().to(memory_format=torch.channels_last)
+    x = torch.randn(B, C_in, H, W, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    assert conv._implicit_ok(x)
+    y = conv(x)
+    assert y.shape == (B, C_out, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_()
+    wr = conv.weight.detach().float().requires_grad_()
+    yr = F.conv2d(xr, wr, padding=1)
+    yr.backward(gy.float())
+    k = 9 * C_in
+    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=2e-2 * math.sqrt(k) * 0.05 + 1e-2)
+    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=2e-2, atol=2e-2 * math.sqrt(9 * C_out) * 0.05 + 1e-2)
+    scale = math.sqrt(B * H * W)
+    torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=2e-2, atol=2e-2 * scale)
+    rel = (conv.weight.grad.float() - wr.grad).norm() / wr.grad.norm()
+    assert rel < 1e-2, rel
+
+
+def test_conv3x3_falls_back_for_strided_and_fp32_layers():
+    from distributed_pytorch_amd.ops.conv import Conv3x3
+
+    conv = Conv3x3(64, 64, stride=2, min_channels=64).to(DEV).bfloat16().to(memory_format=torch.channels_last)
+    x = torch.randn(2, 64, 8, 8, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert not conv._implicit_ok(x) and conv(x).shape == (2, 64, 4, 4)
+    conv32 = Conv3x3(64, 64).to(DEV)
+    assert not conv32._implicit_ok(torch.randn(2, 64, 8, 8, device=DEV))

@@ -52,7 +52,8 @@ def parse_args(argv=None):
     p.add_argument("--reduce-dtype", default=None, choices=["fp32", "bf16"], help="gradient all-reduce dtype")
     p.add_argument("--bucket-mb", type=float, default=None)
     p.add_argument("--shard-optimizer", action="store_true",
-                   help="N > 1: every rank keeps optimizer state for, and updates, only the parameters it owns; owners broadcast the new values")
+                   help="N > 1: gradients are reduce-scattered, every rank keeps optimizer state for and updates its 1/N range of every "
+                        "bucket, parameters are all-gathered (same bytes on the links as the all-reduce)")
     p.add_argument("--no-busbw", action="store_true", help="skip the all-reduce bus-bandwidth measurement after the timed steps (N > 1)")
     p.add_argument("--backend", default=None, choices=["rccl", "gloo"])
     p.add_argument("--force-ddp", action="store_true",
@@ -180,6 +181,9 @@ def run_rank(rank: int, world_size: int, argv):
         ddp_kwargs["bucket_cap_mb"] = args.bucket_mb
     if args.max_collective_mb:
         ddp_kwargs["max_collective_mb"] = args.max_collective_mb
+    if args.shard_optimizer and distributed_run:
+        # reduce-scatter -> range update -> all-gather on the wrapper's own buffers (parallel/zero.py, arena mode)
+        ddp_kwargs["shard_gradients"] = True
     if args.emulate_ranks > 1:
         if not (args.force_ddp and world_size <= 1 and use_gpu):
             raise SystemExit("--emulate-ranks needs --force-ddp on one GPU")
@@ -386,6 +390,10 @@ def _overlap_report(pg, step, device, model, n_steps=3):
     if hasattr(model, "bucket_sizes"):
         out["bucket_mib"] = [round(b / 2**20, 1) for b in model.bucket_sizes()]
         out["buckets_rebuilt"] = bool(getattr(model, "buckets_rebuilt", False))
+        # bytes a rank puts on the links per step: 2 (N-1)/N of this for an all-reduce, and the same for a
+        # reduce-scatter plus an all-gather of the same buffers ((N-1)/N each)
+        out["gradient_mib_per_step"] = round(sum(model.bucket_sizes()) / 2**20, 1)
+        out["collective_kind"] = "reduce_scatter + all_gather" if getattr(model, "shard_gradients", False) else "all_reduce"
         out["grads_written_in_place"] = int(model.reducer.num_grads_in_place())
         out["grads_packed_by_copy"] = int(model.reducer.num_grads_packed())
     return out

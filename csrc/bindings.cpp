@@ -37,6 +37,8 @@ PYBIND11_MODULE(_C, m) {
       .def("barrier", &RcclComm::barrier, py::call_guard<py::gil_scoped_release>())
       .def("all_reduce_async", &RcclComm::all_reduce_async, py::arg("tensor"), py::arg("op"), py::arg("slot"))
       .def("broadcast_async", &RcclComm::broadcast_async, py::arg("tensor"), py::arg("root"), py::arg("slot"))
+      .def("reduce_scatter_async", &RcclComm::reduce_scatter_async, py::arg("tensor"), py::arg("op"), py::arg("slot"))
+      .def("all_gather_async", &RcclComm::all_gather_async, py::arg("tensor"), py::arg("slot"))
       .def("wait_slot", &RcclComm::wait_slot)
       .def("wait_all_slots", &RcclComm::wait_all_slots)
       .def("synchronize_comm_stream", &RcclComm::synchronize_comm_stream, py::call_guard<py::gil_scoped_release>())
@@ -84,6 +86,7 @@ PYBIND11_MODULE(_C, m) {
 
   py::class_<Transport, std::shared_ptr<Transport>>(m, "Transport")
       .def("native_average", &Transport::native_average)
+      .def("rank", &Transport::rank)
       .def("world", &Transport::world);
   m.def("make_rccl_transport", &make_rccl_transport);
   m.def("make_c10d_transport", &make_c10d_transport);
@@ -104,8 +107,10 @@ PYBIND11_MODULE(_C, m) {
 
   py::class_<Reducer, std::shared_ptr<Reducer>>(m, "Reducer")
       .def(py::init([](std::vector<at::Tensor> params, std::vector<BucketSpec> buckets, std::shared_ptr<Transport> t,
-                       bool gradient_as_bucket_view, bool unpack_to_grads, int64_t max_collective_bytes, bool track_unused) {
+                       bool gradient_as_bucket_view, bool unpack_to_grads, int64_t max_collective_bytes, bool track_unused,
+                       bool shard_gradients) {
              ReducerOptions o;
+             o.shard_gradients = shard_gradients;
              o.gradient_as_bucket_view = gradient_as_bucket_view;
              o.unpack_to_grads = unpack_to_grads;
              o.max_collective_bytes = max_collective_bytes;
@@ -114,8 +119,11 @@ PYBIND11_MODULE(_C, m) {
            }),
            py::arg("params"), py::arg("buckets"), py::arg("transport"), py::arg("gradient_as_bucket_view") = true,
            py::arg("unpack_to_grads") = true, py::arg("max_collective_bytes") = 0,
-           py::arg("track_unused") = false)
-      .def("prepare_for_backward", &Reducer::prepare_for_backward, py::arg("sync") = true)
+           py::arg("track_unused") = false, py::arg("shard_gradients") = false)
+      // Everything that can wait for a collective releases the GIL: the host-side (gloo) group finishes its work
+      // objects on worker threads that take the GIL to drop tensors handed in from Python; a caller that blocks
+      // with the GIL held can leave both of those threads waiting for it and nobody to run the collective.
+      .def("prepare_for_backward", &Reducer::prepare_for_backward, py::arg("sync") = true, py::call_guard<py::gil_scoped_release>())
       .def("armed", &Reducer::armed)
       .def("ready_order", &Reducer::ready_order)
       .def("num_buckets", &Reducer::num_buckets)
@@ -134,9 +142,10 @@ PYBIND11_MODULE(_C, m) {
       .def("set_deferred_wait", &Reducer::set_deferred_wait, py::arg("on"))
       .def("deferred_wait", &Reducer::deferred_wait)
       .def("waits_pending", &Reducer::waits_pending)
-      .def("wait_bucket", &Reducer::wait_bucket, py::arg("bucket"))
-      .def("wait_pending", &Reducer::wait_pending)
+      .def("wait_bucket", &Reducer::wait_bucket, py::arg("bucket"), py::call_guard<py::gil_scoped_release>())
+      .def("wait_pending", &Reducer::wait_pending, py::call_guard<py::gil_scoped_release>())
       .def("bucket_of", &Reducer::bucket_of, py::arg("param_index"))
+      .def("all_gather_bucket", &Reducer::all_gather_bucket, py::arg("bucket"), py::arg("flat"), py::call_guard<py::gil_scoped_release>())
       .def("num_grads_in_place", &Reducer::num_grads_in_place)
       .def("num_grads_packed", &Reducer::num_grads_packed)
       .def("broadcast_parameters", &Reducer::broadcast_parameters, py::arg("root") = 0,

@@ -350,6 +350,62 @@ void RcclComm::broadcast_async(at::Tensor t, int root, int slot) {
   finish_async(slot, done, t0);
 }
 
+void RcclComm::reduce_scatter_async(at::Tensor t, int op, int slot) {
+  check_tensor(t);
+  if (t.numel() % world_ != 0) throw std::runtime_error("RcclComm::reduce_scatter_async: buffer must hold world * shard elements");
+  DeviceGuard g(device_);
+  begin_slot(slot);
+  hipEvent_t done = slot_events_[static_cast<size_t>(slot)], fence = fence_events_[static_cast<size_t>(slot)];
+  DPA_HIP_CHECK(hipEventRecord(fence, current_stream(device_)));
+  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence, 0));
+  hipEvent_t t0 = nullptr;
+  if (timing_) {
+    t0 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(t0, comm_stream_));
+  }
+  const size_t shard = static_cast<size_t>(t.numel() / world_);
+  if (shard > 0 && emulating()) {
+    const double bytes = static_cast<double>(t.numel()) * static_cast<double>(t.element_size());
+    const double ms = (emu_ranks_ - 1.0) / emu_ranks_ * bytes / (emu_busbw_gbps_ * 1e9) * 1e3 + emu_latency_us_ * 1e-3;
+    kernels::launch_emulated_collective(t.data_ptr(), static_cast<long long>(bytes), emu_workgroups_, 1, ms, comm_stream_);
+  } else if (shard > 0 && !one_rank_identity_) {
+    std::lock_guard<std::timed_mutex> lk(comm_mu_);
+    if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
+    char* base = static_cast<char*>(t.data_ptr());
+    DPA_NCCL_CHECK(ncclReduceScatter(base, base + static_cast<size_t>(rank_) * shard * t.element_size(), shard, to_nccl_dtype(t.scalar_type()),
+                                     static_cast<ncclRedOp_t>(op), comm_, comm_stream_));
+  }
+  finish_async(slot, done, t0);
+}
+
+void RcclComm::all_gather_async(at::Tensor t, int slot) {
+  check_tensor(t);
+  if (t.numel() % world_ != 0) throw std::runtime_error("RcclComm::all_gather_async: buffer must hold world * shard elements");
+  DeviceGuard g(device_);
+  begin_slot(slot);
+  hipEvent_t done = slot_events_[static_cast<size_t>(slot)], fence = fence_events_[static_cast<size_t>(slot)];
+  DPA_HIP_CHECK(hipEventRecord(fence, current_stream(device_)));
+  DPA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, fence, 0));
+  hipEvent_t t0 = nullptr;
+  if (timing_) {
+    t0 = timing_event();
+    DPA_HIP_CHECK(hipEventRecord(t0, comm_stream_));
+  }
+  const size_t shard = static_cast<size_t>(t.numel() / world_);
+  if (shard > 0 && emulating()) {
+    const double bytes = static_cast<double>(t.numel()) * static_cast<double>(t.element_size());
+    const double ms = (emu_ranks_ - 1.0) / emu_ranks_ * bytes / (emu_busbw_gbps_ * 1e9) * 1e3 + emu_latency_us_ * 1e-3;
+    kernels::launch_emulated_collective(t.data_ptr(), static_cast<long long>(bytes), emu_workgroups_, 1, ms, comm_stream_);
+  } else if (shard > 0 && !one_rank_identity_) {
+    std::lock_guard<std::timed_mutex> lk(comm_mu_);
+    if (!comm_) throw std::runtime_error("RcclComm: communicator was aborted");
+    char* base = static_cast<char*>(t.data_ptr());
+    DPA_NCCL_CHECK(ncclAllGather(base + static_cast<size_t>(rank_) * shard * t.element_size(), base, shard, to_nccl_dtype(t.scalar_type()),
+                                 comm_, comm_stream_));
+  }
+  finish_async(slot, done, t0);
+}
+
 void RcclComm::wait_slot(int slot) {
   if (slot < 0 || static_cast<size_t>(slot) >= slot_events_.size() || !slot_pending_[static_cast<size_t>(slot)]) return;
   DeviceGuard g(device_);

@@ -60,6 +60,11 @@ class RcclComm {
   // runs the all-reduce; `slot` names the completion event to wait on later.
   void all_reduce_async(at::Tensor t, int op, int slot);
   void broadcast_async(at::Tensor t, int root, int slot);
+  // In-place sharded collectives on the communication stream: `t` is a flat buffer of world * shard elements.
+  // reduce_scatter: this rank's shard [rank*shard, (rank+1)*shard) receives the reduction over ranks of that range
+  // (the rest of `t` keeps local values); all_gather: every rank's shard is sent to its position in all ranks' `t`.
+  void reduce_scatter_async(at::Tensor t, int op, int slot);
+  void all_gather_async(at::Tensor t, int slot);
   void wait_slot(int slot);         // current stream waits for slot's completion event
   void wait_all_slots();            // ... for every slot used since the last call
   void synchronize_comm_stream();   // host waits (debug / teardown)

@@ -6,6 +6,8 @@
 #include <torch/csrc/autograd/variable.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "kernels/kernels.h"
@@ -55,6 +57,11 @@ class RcclTransport final : public Transport {
     comm_->all_reduce_async(flat, average ? static_cast<int>(ncclAvg) : static_cast<int>(ncclSum), slot);
   }
   void broadcast(at::Tensor flat, int root) override { comm_->broadcast(flat, root); }
+  void reduce_scatter_async(at::Tensor flat, int slot, bool average) override {
+    comm_->reduce_scatter_async(flat, average ? static_cast<int>(ncclAvg) : static_cast<int>(ncclSum), slot);
+  }
+  void all_gather_async(at::Tensor flat, int slot) override { comm_->all_gather_async(flat, slot); }
+  int rank() const override { return comm_->rank(); }
   void all_reduce_sum_blocking(at::Tensor t) override {
     comm_->all_reduce(t, static_cast<int>(ncclSum));  // on the current stream; the caller's copy to the host waits for it
   }
@@ -72,7 +79,16 @@ class RcclTransport final : public Transport {
 
 class C10dTransport final : public Transport {
  public:
-  explicit C10dTransport(c10::intrusive_ptr<c10d::ProcessGroup> pg) : pg_(std::move(pg)) {}
+  explicit C10dTransport(c10::intrusive_ptr<c10d::ProcessGroup> pg) : pg_(std::move(pg)) {
+    const char* e = std::getenv("DIST_C10D_TRACE");
+    trace_ = e != nullptr && e[0] == '1';
+  }
+  // DIST_C10D_TRACE=1: one stderr line per collective this transport enters (rank, operation, elements), for
+  // comparing the ranks' sequences when a host-side run hangs.
+  void note(const char* what, int64_t numel) const {
+    if (trace_) std::fprintf(stderr, "[c10d-transport %p rank %d] %s numel=%lld pending=%zu\n", static_cast<const void*>(this), pg_->getRank(), what,
+                             static_cast<long long>(numel), works_.size());
+  }
   bool native_average() const override { return false; }
   // GPU tensors on a host-side group (gloo) are staged through host memory HERE, with plain synchronous copies on
   // the current stream, and the group only ever sees CPU tensors.  Handing it the GPU tensor makes the group stage
@@ -91,6 +107,7 @@ class C10dTransport final : public Transport {
     t.copy_(h);
   }
   void all_reduce_async(at::Tensor flat, int /*slot*/, bool /*average: pre-divided by the reducer*/) override {
+    note("all_reduce_async", flat.numel());
     if (flat.is_cuda()) {
       reduce_through_host(*pg_, flat);
       return;
@@ -101,6 +118,7 @@ class C10dTransport final : public Transport {
     works_.push_back(pg_->allreduce(ts, o));
   }
   void broadcast(at::Tensor flat, int root) override {
+    note("broadcast", flat.numel());
     at::Tensor h = flat.is_cuda() ? flat.to(at::kCPU) : flat;
     std::vector<at::Tensor> ts{h};
     c10d::BroadcastOptions o;
@@ -108,6 +126,22 @@ class C10dTransport final : public Transport {
     pg_->broadcast(ts, o)->wait();
     if (flat.is_cuda() && pg_->getRank() != root) flat.copy_(h);
   }
+  // The host-side group is the correctness path: a reduce-scatter is served by the all-reduce (every rank then holds
+  // every range, a superset of what the caller may rely on).
+  void reduce_scatter_async(at::Tensor flat, int slot, bool average) override { all_reduce_async(flat, slot, average); }
+  void all_gather_async(at::Tensor flat, int /*slot*/) override {
+    note("all_gather", flat.numel());
+    wait_all();
+    const int64_t n = pg_->getSize(), shard = flat.numel() / n;
+    at::Tensor h = flat.is_cuda() ? flat.to(at::kCPU) : flat;
+    // one all-gather: the rank's own range goes in as a copy, the ranges of the flat buffer are the outputs
+    std::vector<at::Tensor> in{h.narrow(0, pg_->getRank() * shard, shard).clone()};
+    std::vector<std::vector<at::Tensor>> out(1);
+    for (int64_t r = 0; r < n; ++r) out[0].push_back(h.narrow(0, r * shard, shard));
+    pg_->allgather(out, in)->wait();
+    if (flat.is_cuda()) flat.copy_(h);
+  }
+  int rank() const override { return pg_->getRank(); }
   void all_reduce_sum_blocking(at::Tensor t) override {
     if (t.is_cuda()) {
       reduce_through_host(*pg_, t);
@@ -127,12 +161,16 @@ class C10dTransport final : public Transport {
  private:
   c10::intrusive_ptr<c10d::ProcessGroup> pg_;
   std::vector<c10::intrusive_ptr<c10d::Work>> works_;
+  bool trace_ = false;
 };
 
 class LocalTransport final : public Transport {
  public:
   bool native_average() const override { return true; }
   void all_reduce_async(at::Tensor, int, bool) override {}
+  void reduce_scatter_async(at::Tensor, int, bool) override {}
+  void all_gather_async(at::Tensor, int) override {}
+  int rank() const override { return 0; }
   void broadcast(at::Tensor, int) override {}
   void all_reduce_sum_blocking(at::Tensor) override {}
   void wait_all() override {}
@@ -186,6 +224,10 @@ Reducer::Reducer(std::vector<at::Tensor> params, std::vector<BucketSpec> buckets
     for (int64_t off = 0; off < total || (total == 0 && off == 0); off += per) {
       bs.slices.emplace_back(off, std::min(per, total - off));
       if (total == 0) break;
+    }
+    if (opt_.shard_gradients) {
+      if (total % transport_->world() != 0) throw std::invalid_argument("Reducer: a sharded bucket must hold a multiple of world-size elements");
+      bs.slices.assign(1, {0, total});
     }
     bs.slot_base = next_slot;
     next_slot += static_cast<int>(bs.slices.size());
@@ -395,7 +437,8 @@ void Reducer::launch_bucket(size_t b) {
   for (size_t k = 0; k < bs.slices.size(); ++k) {
     const auto& sl = bs.slices[k];
     at::Tensor piece = bs.slices.size() == 1 ? bs.spec.buffer : bs.spec.buffer.narrow(0, sl.first, sl.second);
-    transport_->all_reduce_async(piece, bs.slot_base + static_cast<int>(k), /*average=*/true);
+    if (opt_.shard_gradients) transport_->reduce_scatter_async(piece, bs.slot_base + static_cast<int>(k), /*average=*/true);
+    else transport_->all_reduce_async(piece, bs.slot_base + static_cast<int>(k), /*average=*/true);
     ++n_collectives_;
   }
   bs.launched = true;
@@ -450,6 +493,18 @@ void Reducer::finalize_backward() {
   last_ready_order_ = ready_order_;
   last_launch_pos_ = launch_pos_;
   ++n_syncs_;
+}
+
+void Reducer::all_gather_bucket(int64_t b, at::Tensor flat) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (b < 0 || b >= static_cast<int64_t>(buckets_.size())) throw std::out_of_range("Reducer: bucket index out of range");
+  const BucketState& bs = buckets_[static_cast<size_t>(b)];
+  if (flat.numel() != bs.spec.buffer.numel()) throw std::invalid_argument("Reducer: parameter buffer does not match the bucket layout");
+  transport_->all_gather_async(flat, bs.slot_base);
+  ++n_collectives_;
+  waits_pending_ = true;  // the consumer (wait_bucket / wait_pending, or the next prepare_for_backward) orders the compute stream behind it
+  if (bucket_waited_.size() != buckets_.size()) bucket_waited_.assign(buckets_.size(), 0);
+  bucket_waited_[static_cast<size_t>(b)] = 0;
 }
 
 void Reducer::broadcast_parameters(int root) {

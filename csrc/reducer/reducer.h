@@ -36,6 +36,11 @@ class Transport {
   virtual bool native_average() const = 0;
   virtual void all_reduce_async(at::Tensor flat, int slot, bool average) = 0;
   virtual void broadcast(at::Tensor flat, int root) = 0;
+  // Sharded mode, both in place on a flat buffer of world * shard elements: after reduce_scatter rank r's shard
+  // [r*shard, (r+1)*shard) holds the reduced (averaged) values; all_gather publishes every rank's shard to all.
+  virtual void reduce_scatter_async(at::Tensor flat, int slot, bool average) = 0;
+  virtual void all_gather_async(at::Tensor flat, int slot) = 0;
+  virtual int rank() const = 0;
   // Blocking sum all-reduce of a small tensor (the "gradient used anywhere" bitmap).
   virtual void all_reduce_sum_blocking(at::Tensor t) = 0;
   // Make the consumer of the buckets (current stream / host thread) wait for all pending ops.
@@ -71,6 +76,11 @@ struct ReducerOptions {
   // parameter unused everywhere keeps grad = None instead of receiving zeros, so an optimizer with weight
   // decay or momentum leaves it alone.
   bool track_unused = false;
+  // Sharded gradients: every bucket goes out as ONE in-place reduce-scatter (its element count must be a multiple
+  // of the world size), after which this rank holds the averaged gradient of its own 1/world range of every bucket
+  // only.  The consumer is a sharded optimizer that updates that range and all-gathers the parameters
+  // (parallel/zero.py); .grad tensors outside the rank's range hold local, unreduced values.
+  bool shard_gradients = false;
 };
 
 class Reducer {
@@ -124,6 +134,8 @@ class Reducer {
   int64_t bucket_of(int64_t param_index) const {
     return param_index >= 0 && param_index < static_cast<int64_t>(locator_.size()) ? locator_[static_cast<size_t>(param_index)].first : -1;
   }
+  // Sharded mode: in-place all-gather of a flat parameter buffer laid out like bucket b, on the bucket's slot.
+  void all_gather_bucket(int64_t b, at::Tensor flat);
   // Removes the autograd hooks (also done by the destructor).
   void detach();
 

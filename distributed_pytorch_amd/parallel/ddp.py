@@ -83,7 +83,8 @@ class DistributedDataParallel(nn.Module):
                  first_bucket_mb: Optional[float] = None, broadcast_buffers: bool = True,
                  find_unused_parameters: bool = False, gradient_as_bucket_view: bool = True,
                  reduce_dtype=None, init_sync: bool = True, process_group=None, transport=None,
-                 rebuild_buckets: Optional[bool] = None, max_collective_mb: Optional[float] = None, **kwargs):
+                 rebuild_buckets: Optional[bool] = None, max_collective_mb: Optional[float] = None,
+                 shard_gradients: bool = False, **kwargs):
         super().__init__()
         if len(args) > len(_TORCH_POSITIONAL):
             raise TypeError(f"DistributedDataParallel: at most {len(_TORCH_POSITIONAL) + 2} positional arguments")
@@ -159,6 +160,14 @@ class DistributedDataParallel(nn.Module):
         self._max_collective_bytes = (int(max_collective_mb * (1 << 20)) if max_collective_mb is not None
                                       else default_max_collective_bytes(self._bucket_bytes))
         self._grad_as_view = bool(gradient_as_bucket_view)
+        # Sharded gradients (for parallel/zero.py's ShardedOptimizer): every bucket is reduce-scattered in place, so a
+        # rank ends a backward pass with the averaged gradient of its own 1/world range of every bucket; parameters are
+        # re-homed into flat buffers with the buckets' layout, which the optimizer updates range-wise and all-gathers.
+        self.shard_gradients = bool(shard_gradients)
+        if self.shard_gradients:
+            if not self._grad_as_view or self.reduce_dtype is not None or self.find_unused_parameters:
+                raise ValueError("shard_gradients=True needs gradient_as_bucket_view=True, no reduce_dtype and no find_unused_parameters")
+            rebuild_buckets = False   # the layout carries the optimizer's state shards: it is fixed at construction
         if rebuild_buckets is None:
             rebuild_buckets = os.environ.get("DIST_REBUILD_BUCKETS", "1") != "0"
         # Like torch's reducer, the bucket layout is re-planned once, after the first synchronised
@@ -229,18 +238,42 @@ class DistributedDataParallel(nn.Module):
         opts = h.PlanOptions(self._first_bucket_bytes, self._bucket_bytes, 128, True)
         plan = h.plan_buckets(metas, opts) if ready_order is None else h.plan_buckets_from_order(metas, list(ready_order), opts)
         self._plan = plan
-        self._arenas: Dict[int, torch.Tensor] = {
-            key: torch.zeros(numel, dtype=dtypes[key], device=self.device) for key, numel in plan.arena_numel
-        }
-        specs = []
-        for b in plan.buckets:
-            buf = self._arenas[b.group_key].narrow(0, b.arena_offset, b.numel)
-            specs.append(self._C.BucketSpec(list(b.param_indices), list(b.offsets), buf))
+        if self.shard_gradients:
+            # every bucket padded to a multiple of world * 64 elements (equal, 128-byte aligned ranges), buckets back to back
+            unit = self.world_size * 64
+            planned = list(plan.buckets)
+            sizes = [-(-b.numel // unit) * unit for b in planned]
+            offs, total = [], {}
+            for b, n in zip(planned, sizes):
+                offs.append(total.get(b.group_key, 0))
+                total[b.group_key] = offs[-1] + n
+            self._arenas = {key: torch.zeros(n, dtype=dtypes[key], device=self.device) for key, n in total.items()}
+            self._param_arenas = {key: torch.zeros(n, dtype=dtypes[key], device=self.device) for key, n in total.items()}
+            bufs = [self._arenas[b.group_key].narrow(0, o, n) for b, o, n in zip(planned, offs, sizes)]
+            self._param_buffers = [self._param_arenas[b.group_key].narrow(0, o, n) for b, o, n in zip(planned, offs, sizes)]
+        else:
+            self._arenas: Dict[int, torch.Tensor] = {
+                key: torch.zeros(numel, dtype=dtypes[key], device=self.device) for key, numel in plan.arena_numel
+            }
+            bufs = [self._arenas[b.group_key].narrow(0, b.arena_offset, b.numel) for b in plan.buckets]
+        specs = [self._C.BucketSpec(list(b.param_indices), list(b.offsets), buf) for b, buf in zip(plan.buckets, bufs)]
         self._bucket_buffers = [s.buffer for s in specs]
         self._bucket_params = [list(b.param_indices) for b in plan.buckets]
+        self._bucket_offsets = [list(b.offsets) for b in plan.buckets]
         self._reducer = self._C.Reducer(self._params, specs, self._transport, self._grad_as_view, True,
-                                        int(self._max_collective_bytes), self.find_unused_parameters and self.world_size > 1)
+                                        0 if self.shard_gradients else int(self._max_collective_bytes),
+                                        self.find_unused_parameters and self.world_size > 1, self.shard_gradients)
         self._reducer.set_deferred_wait(getattr(self, "_defer_wait", False))
+        if self.shard_gradients:
+            with torch.no_grad():   # parameters move into the flat buffers (same offsets as their gradients)
+                for pbuf, idxs, poffs in zip(self._param_buffers, self._bucket_params, self._bucket_offsets):
+                    for pi, off in zip(idxs, poffs):
+                        p = self._params[pi]
+                        if not p.is_contiguous():
+                            raise ValueError("shard_gradients=True needs contiguous parameters")
+                        v = pbuf.narrow(0, off, p.numel()).view(p.shape)
+                        v.copy_(p.detach())
+                        p.data = v
 
     def _agreed_ready_order(self) -> List[int]:
         """Rank 0's observed gradient-ready order, on every rank (the layouts must be identical)."""
@@ -415,6 +448,21 @@ class DistributedDataParallel(nn.Module):
 
     def bucket_of(self, param_index: int) -> int:
         return int(self._reducer.bucket_of(int(param_index)))
+
+    # ------------------------------------------------------------------ sharded gradients (parallel/zero.py)
+    def shard_layout(self):
+        """Per bucket: (gradient buffer, parameter buffer, elements per rank, [(parameter index, offset, numel)])."""
+        if not self.shard_gradients:
+            raise RuntimeError("shard_layout() needs shard_gradients=True")
+        out = []
+        for gbuf, pbuf, idxs, offs in zip(self._bucket_buffers, self._param_buffers, self._bucket_params, self._bucket_offsets):
+            out.append((gbuf, pbuf, gbuf.numel() // self.world_size, [(pi, off, self._params[pi].numel()) for pi, off in zip(idxs, offs)]))
+        return out
+
+    def all_gather_parameters(self, bucket: int) -> None:
+        """In-place all-gather of bucket ``bucket``'s parameter buffer on the communication stream (every rank
+        contributes its own range); ordered behind what the current stream has queued so far."""
+        self._reducer.all_gather_bucket(int(bucket), self._param_buffers[int(bucket)])
 
     # ------------------------------------------------------------------ introspection
     @property

@@ -442,3 +442,77 @@ def ddp_surface_worker(rank, world_size, out_dir):
         res["join_even"] = False
     _dump(out_dir, rank, res)
     dist.cleanup()
+
+
+def sharded_arena_worker(rank, world_size, out_dir, clip):
+    """Range-sharded optimizer under a wrapper with shard_gradients=True (reduce-scatter -> range update -> all-gather)
+    against a full optimizer under the plain wrapper: same parameters after every step, same global norm, state
+    that converts to and from the unsharded layout, and fewer bytes than the all-reduce + broadcast arrangement."""
+    import distributed as dist
+    from distributed_pytorch_amd.ops import FusedAdamW
+    from distributed_pytorch_amd.parallel import ShardedOptimizer
+    from distributed_pytorch_amd.parallel.ddp import DistributedDataParallel
+
+    dist.init_process_group(rank, world_size, "gloo")
+
+    def make():
+        torch.manual_seed(5)
+        return nn.Sequential(nn.Linear(24, 67), nn.ReLU(), nn.Linear(67, 33), nn.ReLU(), nn.Linear(33, 5))
+
+    full_m, shard_m = make(), make()
+    full = DistributedDataParallel(full_m, bucket_cap_mb=0.004, first_bucket_mb=0.001)
+    shard = DistributedDataParallel(shard_m, bucket_cap_mb=0.004, first_bucket_mb=0.001, shard_gradients=True)
+    o_full = FusedAdamW(full_m.parameters(), lr=1e-2, weight_decay=0.05, max_grad_norm=clip)
+    o_shard = ShardedOptimizer(shard_m.parameters(), lr=1e-2, weight_decay=0.05, max_grad_norm=clip)
+    res = {"arena": o_shard._arena is not None, "n_buckets": len(o_shard._arena["buckets"]),
+           "state_numel": sum(bk["state"]["exp_avg"].numel() for bk in o_shard._arena["buckets"]),
+           "model_numel": sum(p.numel() for p in shard_m.parameters()),
+           "params_are_views": all(any(p.data_ptr() >= b.data_ptr() and p.data_ptr() < b.data_ptr() + b.numel() * 4
+                                       for b in shard._param_buffers) for p in shard_m.parameters())}
+    g = torch.Generator().manual_seed(11 + rank)
+
+    def run(n, pairs):
+        for step in range(n):
+            x = torch.randn(6, 24, generator=g)
+            y = torch.randint(0, 5, (6,), generator=g)
+            for m, o in pairs:
+                o.zero_grad()
+                nn.functional.cross_entropy(m(x), y).backward()
+                o.step()
+
+    def max_diff(a, b):
+        return max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(a.parameters(), b.parameters()))
+
+    run(3, ((full, o_full), (shard, o_shard)))
+    res["diff_after_3"] = max_diff(full_m, shard_m)
+    res["grad_norm_diff"] = (float((o_shard.last_grad_norm.reshape(()) - o_full.last_grad_norm.reshape(())).abs())
+                             if clip is not None else 0.0)
+    for o in (o_full, o_shard):
+        torch.optim.lr_scheduler.StepLR(o, step_size=1, gamma=0.5).step()
+    run(2, ((full, o_full), (shard, o_shard)))
+    res["diff_after_5"] = max_diff(full_m, shard_m)
+    cons = o_shard.consolidated_state_dict()
+    ref_sd = o_full.state_dict()
+    res["cons_keys_equal"] = sorted(cons["state"].keys()) == sorted(ref_sd["state"].keys())
+    res["cons_state_diff"] = max(float((cons["state"][k][f] - ref_sd["state"][k][f]).abs().max())
+                                 for k in ref_sd["state"] for f in ("exp_avg", "exp_avg_sq", "step"))
+    # resume: unsharded layout -> plain optimizer and -> a fresh range-sharded one; the rank's own format round-trips
+    plain_m, again_m = make(), make()
+    plain_m.load_state_dict(shard_m.state_dict())
+    again_m.load_state_dict(shard_m.state_dict())
+    plain = DistributedDataParallel(plain_m, bucket_cap_mb=0.004, first_bucket_mb=0.001)
+    again = DistributedDataParallel(again_m, bucket_cap_mb=0.004, first_bucket_mb=0.001, shard_gradients=True)
+    o_plain = FusedAdamW(plain_m.parameters(), lr=1e-2, weight_decay=0.05, max_grad_norm=clip)
+    o_plain.load_state_dict(cons)
+    o_again = ShardedOptimizer(again_m.parameters(), lr=1e-2, weight_decay=0.05, max_grad_norm=clip)
+    o_again.load_state_dict(cons)
+    res["lr_restored"] = [grp["lr"] for grp in o_again.param_groups]
+    o_shard.load_state_dict(o_shard.state_dict())
+    run(2, ((full, o_full), (shard, o_shard), (plain, o_plain), (again, o_again)))
+    res["diff_after_resume"] = max(max_diff(full_m, shard_m), max_diff(full_m, plain_m), max_diff(full_m, again_m))
+    res["in_sync"] = shard.check_replicas_in_sync()
+    c0 = int(shard.reducer.num_collectives())
+    run(1, ((shard, o_shard),))
+    res["collectives_per_step"] = int(shard.reducer.num_collectives()) - c0
+    _dump(out_dir, rank, res)
+    dist.cleanup()

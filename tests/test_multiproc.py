@@ -352,3 +352,24 @@ def test_ddp_keyword_and_method_surface_world2(tmp_path):
         assert r["hashes_say_in_sync"] is False and r["diverged"] == ["0.weight"]
         assert r["join_even"] is True
     assert _read(tmp_path, 2)[0]["warned"] == ["mixed_precision", "static_graph"]
+
+
+@pytest.mark.parametrize("world,clip", [(2, None), (3, None), (2, 0.5)])
+def test_range_sharded_optimizer_on_reduce_scatter_matches_full_optimizer(tmp_path, world, clip):
+    dist.launch(mp_workers.sharded_arena_worker, str(tmp_path), clip, nprocs=world)
+    # Two ranks, no clipping: the update is the full optimizer's, element for element -- bit-equal.  With clipping the
+    # global norm is summed range by range and over the ranks instead of parameter by parameter: equal to the last
+    # bits.  Three ranks: the padded buckets are cut into other ring segments than the plain wrapper's, so the
+    # three-term sums round differently here and there, and Adam's first steps (update ~ sign of the gradient)
+    # turn a last-bit difference of a near-zero gradient into a visible one.
+    tol = 0.0 if (clip is None and world == 2) else (1e-6 if world == 2 else 2e-4)
+    for r in _read(tmp_path, world):
+        assert r["arena"] and r["n_buckets"] >= 2 and r["params_are_views"]
+        # fp32 moments exist for one range of every bucket: the model over the ranks, plus padding
+        assert r["model_numel"] / world <= r["state_numel"] <= r["model_numel"] / world + 256 * r["n_buckets"]
+        assert r["diff_after_3"] <= tol and r["diff_after_5"] <= tol and r["diff_after_resume"] <= tol
+        assert r["grad_norm_diff"] < 1e-6 and r["in_sync"]
+        assert r["cons_keys_equal"] and r["cons_state_diff"] <= tol
+        assert r["lr_restored"] == [5e-3]
+        # per step: one reduce-scatter and one all-gather per bucket (the plain wrapper: one all-reduce per bucket)
+        assert r["collectives_per_step"] == 2 * r["n_buckets"]

@@ -200,8 +200,10 @@ void launch_rank1_mlp_bwd(const void* dy, const void* x, const void* w1, const v
 bool embedding_supported(long long rows, long long T, long long C, long long V, long long P);
 void launch_embedding_fwd(const long long* idx, const void* wte, const void* wpe, void* out, long long rows, int T, int C, long long V,
                           hipStream_t stream);
+long long embedding_bwd_chunks(long long rows);
+// head_part / body_part: fp32 [embedding_bwd_chunks(rows)][C] scratch, head_tok: int64 [chunks] scratch (long runs of one token).
 void launch_embedding_bwd(const void* grad, const long long* tok_sorted, const long long* perm, void* dwte, void* dwpe, long long rows,
-                          int B, int T, int C, long long V, hipStream_t stream);
+                          int B, int T, int C, long long V, float* head_part, float* body_part, long long* head_tok, hipStream_t stream);
 
 void launch_reduce_partials(const float* partial, void* out, long long len, int chunks, int dtype,
                             hipStream_t stream);

@@ -977,9 +977,14 @@ std::tuple<Tensor, Tensor> embedding_backward(Tensor grad, Tensor tok_sorted, Te
   Tensor dwte = at::zeros({V, C}, grad.options());
   Tensor dwpe = at::zeros({P, C}, grad.options());
   DevGuard guard(grad);
+  const int64_t chunks = kernels::embedding_bwd_chunks(rows);
+  Tensor parts = at::empty({2, chunks, C}, grad.options().dtype(at::kFloat));
+  Tensor head_tok = at::empty({chunks}, grad.options().dtype(at::kLong));
   kernels::launch_embedding_bwd(grad.data_ptr(), reinterpret_cast<const long long*>(tok_sorted.data_ptr<int64_t>()),
                                 reinterpret_cast<const long long*>(perm.data_ptr<int64_t>()), dwte.data_ptr(), dwpe.data_ptr(), rows,
-                                static_cast<int>(rows / T), static_cast<int>(T), static_cast<int>(C), V, stream_of(grad));
+                                static_cast<int>(rows / T), static_cast<int>(T), static_cast<int>(C), V, parts.data_ptr<float>(),
+                                parts.data_ptr<float>() + chunks * C, reinterpret_cast<long long*>(head_tok.data_ptr<int64_t>()),
+                                stream_of(grad));
   return {dwte, dwpe};
 }
 

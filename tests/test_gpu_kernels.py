@@ -1038,6 +1038,39 @@ def test_token_position_embedding_forward_backward(B, T, C, V, P):
     assert torch.equal(again[0], dwte) and torch.equal(again[1], dwpe)
 
 
+@pytest.mark.parametrize("B,T,C,V,frac", [(16, 1024, 768, 50304, 0.5), (4, 300, 64, 7, 0.9), (2, 256, 128, 100, 1.0), (3, 513, 64, 50, 0.3)])
+def test_token_embedding_backward_with_very_frequent_tokens(B, T, C, V, frac):
+    """Padded / real-text batches: one id takes a large share of all positions (up to all of them), so its run in the
+    sorted list spans many 256-position chunks; the chunk partials and their ordered join must give the same sums
+    as an fp32 accumulation, bit-identically from run to run, and in a time that does not grow with the run."""
+    import time
+
+    from distributed_pytorch_amd.ops.embedding import token_position_embedding
+
+    torch.manual_seed(B + T)
+    wte = torch.randn(V, C, device=DEV).bfloat16().requires_grad_()
+    wpe = torch.randn(T, C, device=DEV).bfloat16().requires_grad_()
+    idx = torch.randint(0, V, (B, T), device=DEV)
+    hot = V // 2
+    idx[torch.rand(B, T, device=DEV) < frac] = hot                   # the padding / most frequent token
+    idx[0, :3] = torch.tensor([0, V - 1, hot], device=DEV)
+    g = torch.randn(B, T, C, device=DEV).bfloat16()
+    dwte, _ = torch.autograd.grad(token_position_embedding(idx, wte, wpe), (wte, wpe), g)
+    ref = torch.zeros(V, C, device=DEV, dtype=torch.float64).index_add_(0, idx.reshape(-1), g.reshape(-1, C).double())
+    n_hot = int((idx == hot).sum())
+    assert n_hot >= frac * B * T * 0.8
+    torch.testing.assert_close(dwte.double(), ref, rtol=2 ** -7, atol=2e-3 * max(1.0, float(ref.abs().max())))
+    again, _ = torch.autograd.grad(token_position_embedding(idx, wte, wpe), (wte, wpe), g)
+    assert torch.equal(again, dwte)
+    if B * T >= 16384:   # 8192 occurrences of one token: still a sub-millisecond backward
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            torch.autograd.grad(token_position_embedding(idx, wte, wpe), (wte, wpe), g)
+        torch.cuda.synchronize()
+        assert (time.perf_counter() - t0) / 5 < 5e-3
+
+
 def test_token_position_embedding_fallback_and_range_check(monkeypatch):
     from distributed_pytorch_amd.ops.embedding import native_embedding_supported, token_position_embedding
 

@@ -128,7 +128,10 @@ def build_gpu(force=False, verbose=False, jobs_n=8):
     # masked scores are -inf, which these flags leave alone), and without -fno-honor-nans every fmaxf gets a
     # canonicalising v_max in front; SLP packing of adjacent f32 operations into v_pk_*_f32 is off because the
     # packed forms issue slower than two plain instructions next to MFMAs.
-    per_file = {"attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+    # -amdgpu-mfma-vgpr-form: the one-wave-per-SIMD forward kernel has a 512-register budget, with which the
+    # compiler would give every matrix instruction an AGPR destination and copy the score accumulators to
+    # ordinary registers for the softmax; the file's other kernels (256-register budget) already get this form.
+    per_file = {"attention.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
     objs, cmds = [], []
     draw_asm = None
     for s in kernels:

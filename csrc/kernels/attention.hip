@@ -24,6 +24,8 @@
 // queries (4 waves x 32) of one (batch, head) and walks the key tiles (64 keys) up to the
 // diagonal; tiles are double-buffered in LDS with the loads of tile j+1 in flight during the
 // math of tile j; workgroups with the most tiles are launched first.
+#include <cstdlib>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -143,7 +145,11 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 
 // Raw v_exp_f32 (2^x): inputs here are <= 0 or -inf, where the instruction is exact enough and
 // needs none of the denormal-range fix-ups of exp2f().
+#ifdef WIDE_KO_EXP  // diagnostic build only: what does the kernel cost without the exponentials?
+__device__ __forceinline__ float fast_exp2(float x) { return x; }
+#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
@@ -464,6 +470,461 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
   if (threadIdx.x == 64 * 3 && blockIdx.x < (1 << 12)) {
     unsigned long long* r = g_attn_stamps[blockIdx.x];
     r[0] = st_loop; r[1] = st_tiles; r[2] = rt0; r[3] = __builtin_amdgcn_s_memrealtime(); r[4] = __builtin_amdgcn_s_memtime() - c0; r[5] = st_sync;
+  }
+#endif
+}
+
+// =====================================================================================
+// Forward, one wave per SIMD ("wide" variant, used when it is resident -- see launch_attention_fwd).
+//
+// The kernel above keeps two waves per SIMD and lets the hardware overlap one wave's matrix work with the
+// other's softmax; measured, a SIMD then spends ~1460 cycles per 2048 (query, key) pairs although the
+// matrix pipe needs 576 and the vector ALU ~640.  Here ONE wave owns 64 queries = two query blocks of 32
+// (the accumulator column = lane of v_mfma_f32_32x32x16_bf16) and overlaps the stages itself: the two query
+// blocks run half a step out of phase, so that each half-step pairs the softmax of one query block (vector
+// ALU) with the matrix work of the other, and the two never depend on each other:
+//     half 0 of step b:  P(b)[0] = exp2(S(b)[0] c - m[0])   |  S(b)[1]   = K(b)   Q[1]^T ,  O[1] += V(b-1)^T P(b-1)[1]
+//     half 1 of step b:  P(b)[1] = exp2(S(b)[1] c - m[1])   |  S(b+1)[0] = K(b+1) Q[0]^T ,  O[0] += V(b)^T   P(b)[0]
+// (b = 32-key block).  Every value has one home: one score buffer and one probability buffer per query block,
+// one set of K and of V fragments, which are re-read from LDS right behind the last matrix instruction that
+// used the old ones -- four matrix instructions (128 cycles) before the first one that needs the new ones.
+// The running maximum m of a query only moves when a score exceeds it by more than kDeferLog2; the test runs
+// on a query block's fresh scores between two halves, when the probabilities of that query block have just been
+// consumed, so in the rare case it fires only the output accumulators and the row sum are rescaled.
+// Row sums: v_dot2c_f32_bf16 of the packed bf16 probability pairs with (1, 1): 16 instructions per block and
+// wave instead of 32 additions, and exactly the rounded values that multiply V.
+// A workgroup is 4 waves = one per SIMD (the hardware spreads the waves of ONE workgroup over the SIMDs; two
+// 2-wave workgroups per CU were measured to leave a SIMD empty and another with two waves on 93 % of the CUs).
+// Its two wave pairs are independent: each works on 128 queries of its own head -- the same query blocks of two
+// neighbouring heads, so both pairs take the same number of steps and can share the workgroup barrier -- with
+// its own LDS.  K / V blocks (4 KiB each) go global -> LDS by DMA through two rings of four blocks per pair,
+// requested two steps ahead.  Two workgroups per CU: measured with one (one wave per SIMD), a wave spends
+// more than half of every step in places a second wave can fill -- the counted DMA wait and the barrier, the DMA
+// requests themselves (~60 cycles each), the code between the halves -- and the vector ALU port that matrix and
+// vector instructions of a wave share leaves little of the former to hide under the latter anyway (8 matrix + 48
+// vector instructions: 264 + ~290 cycles apart, 460-520 together, tools/kernel_harness/mfma_chain_probe.hip).
+// =====================================================================================
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+constexpr int kWideThreads = 256;
+constexpr int KB = 32;                                  // keys per step
+constexpr int kBlkBytes = KB * HD * 2;                  // 4 KiB
+constexpr int kRing = 4;                                // blocks per ring (K and V each)
+constexpr int kAhead = 2;                               // a block is requested this many steps before the step that reads it
+constexpr int kWideStripBytes = 64 * kOutPitch;         // one wave's 64 output rows
+constexpr int kWidePairLds = 2 * kRing * kBlkBytes;     // one wave pair: its two rings; the output strips reuse them
+static_assert(2 * kWideStripBytes <= kWidePairLds, "both waves' output strips must fit into the pair's rings");
+constexpr int kWideLdsBytes = 2 * kWidePairLds;
+
+// V block [32 keys][64 d], 128-byte rows: the transposing read of a 32-lane half fetches 4 keys x 32 d
+// (64 bytes of 4 consecutive rows); rows r and r + 2 share banks unless their 64-byte halves are swapped.
+__device__ __forceinline__ int v2_off(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
+
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+// 1 KiB (8 rows) global -> LDS: lane fetches 16 bytes at base + off, the wave's pieces land at lds_dst + 16 * lane.
+__device__ __forceinline__ void dma_piece(const char* base, unsigned off, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ float half_swap_max(float x) {   // max with the lane 32 away
+  const unsigned xi = __float_as_uint(x);
+  const u32x2 a = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+  const unsigned xi = __float_as_uint(x);
+  const u32x2 a = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+
+// K fragments of one block (A operand of the score product): lane = key (lane & 31), d = 16*ds + 8*(lane >> 5) ..
+// (k_off(row, c) for c = 2*ds + hi differs from ds = 0 only in address bits 5-6: one lane constant, XOR per ds.)
+__device__ __forceinline__ void wide_load_k(const char* ring, int blk_plus_koff, bf16x8 (&kf)[4]) {
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) kf[ds] = *reinterpret_cast<const bf16x8*>(ring + (blk_plus_koff ^ (ds << 5)));
+}
+// V^T fragments of one block (A operand of the output product): lane = d (32*db + (lane & 31)); the eight k-slots
+// of lane half hi in 16-key step s are keys 16s + 4hi + (0..3) and 16s + 8 + 4hi + (0..3): the keys the score
+// accumulator keeps in registers 8s .. 8s+7 of that half.
+// (db = 1 is 4 chunks further, which the swizzle turns into a flip of address bit 6.)
+__device__ __forceinline__ void wide_load_v(const char* ring, int blk_plus_voff, bf16x8 (&vf)[2][2]) {
+  using lds_ptr = __attribute__((address_space(3))) s16x4*;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const char* a = ring + (blk_plus_voff ^ (db << 6));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + s * 2048));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + s * 2048 + 1024));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      vf[db][s] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+// One half-step (see the header of this section): the softmax of query block Q's scores s[Q] -> pr[Q], under
+// the matrix work of the other query block R: fresh scores s[R] (DO_S) and its output product with pr[R] (DO_O).
+// Half 0 re-reads the K fragments (block address k_addr) behind the score product, half 1 the V fragments
+// (v_addr) in front of it.
+template <int Q, bool DO_S, bool DO_O>
+__device__ __forceinline__ void wide_half(f32x16 (&s)[2], bf16x8 (&pr)[2][2], bf16x8 (&kf)[4], bf16x8 (&vf)[2][2], const bf16x8 (&qf)[2][4],
+                                          f32x16 (&o)[2][2], const float (&m)[2], float (&l)[2], float c, const char* kring,
+                                          const char* vring, int k_addr, int v_addr) {
+  constexpr int R = 1 - Q;
+  // Fragment reads sit four matrix instructions (128 cycles) ahead of their first use: half 1 fetches V(b) in front
+  // of its score product, half 0 K(b+1) behind its score product, which was the last user of K(b).  (Dependent
+  // matrix instructions that accumulate into the same registers issue back to back without a stall.)
+#ifdef WIDE_KO_MFMA  // diagnostic build only: what does the kernel cost without the matrix instructions?
+  constexpr bool kMatrix = false;
+#else
+  constexpr bool kMatrix = true;
+#endif
+  if (Q == 1) wide_load_v(vring, v_addr, vf);
+  if (DO_S && kMatrix) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[R][e] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) s[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[R][ds], s[R], 0, 0, 0);
+  }
+  if (Q == 0) wide_load_k(kring, k_addr, kf);
+  if (DO_O && kMatrix) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) o[R][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][s2], pr[R][s2], o[R][db], 0, 0, 0);
+  }
+  if (!kMatrix) {  // keep the fragment reads alive
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : : "v"(kf[i]), "v"(vf[i & 1][i >> 1]));
+  }
+  bf16x2 ones;
+  ones[0] = static_cast<__bf16>(1.f);
+  ones[1] = static_cast<__bf16>(1.f);
+  const float nm = -m[Q];
+  float lp = l[Q];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x2 v;
+      v[0] = static_cast<__bf16>(fast_exp2(fmaf(s[Q][8 * s2 + 2 * j], c, nm)));
+      v[1] = static_cast<__bf16>(fast_exp2(fmaf(s[Q][8 * s2 + 2 * j + 1], c, nm)));
+      lp = __builtin_amdgcn_fdot2_f32_bf16(v, ones, lp, false);
+      w[j] = __builtin_bit_cast(unsigned, v);
+    }
+    const u32x4 packed = {w[0], w[1], w[2], w[3]};
+    pr[Q][s2] = __builtin_bit_cast(bf16x8, packed);
+  }
+  l[Q] = lp;
+  // 1 matrix instruction : 6 vector instructions (48 per half: 16 fma, 16 exp, 8 convert, 8 dot); LDS reads where they stand
+  if (Q == 1) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+  if (DO_S) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, (DO_O ? 6 : 12), 0);
+    }
+  }
+  if (Q == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  if (DO_O) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, (DO_S ? 6 : 12), 0);
+    }
+  }
+  // The probabilities are only consumed in the next half; without a use here the compiler sinks the softmax out of
+  // this block, past the branches that follow, where no matrix instruction is left to hide it.
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : : "v"(pr[Q][s2]));
+  asm volatile("" : : "v"(l[Q]));
+}
+
+// Between two halves: the scores s[R] of block j are complete and pr[R] has been consumed.  Applies the causal mask
+// when the block touches the diagonal (rel = query - first key of this lane half; register i holds key
+// (i & 3) + 8 * (i >> 2) of it) and moves the running maximum when some score is more than kDeferLog2 above it.
+template <int R>
+__device__ __forceinline__ void wide_between(f32x16 (&s)[2], float (&m)[2], float (&l)[2], f32x16 (&o)[2][2], bool mask, int rel, float c) {
+  if (mask) {
+    asm volatile("" ::: "memory");  // a real (wave-uniform) branch: folded into selects, the compare / select pairs would run in every step
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if ((i & 3) + 8 * (i >> 2) > rel) s[R][i] = -__builtin_huge_valf();
+  }
+  float t = fmaxf(fmaxf(s[R][0], s[R][1]), s[R][2]);
+#pragma unroll
+  for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, s[R][i]), s[R][i + 1]);
+  const float mx = fmaxf(t, s[R][15]) * c;
+  if (__any(mx > m[R] + kDeferLog2)) {
+    const float mg = half_swap_max(mx);  // both lanes of a query must agree
+    const float m_new = mg > m[R] + kDeferLog2 ? mg : m[R];
+    const float alpha = m_new == m[R] ? 1.f : fast_exp2(m[R] - m_new);
+    m[R] = m_new;
+    l[R] *= alpha;
+    // in place, as assembly: a plain multiply lets the register allocator give the products new homes, and every
+    // pass that does NOT take this branch then pays the copies that reconcile the two
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[R][db][e]) : "v"(alpha));
+  }
+}
+
+// Last output product of query block 1, normalisation, log-sum-exp and the wave's 64 output rows (through its LDS strip).
+__device__ __forceinline__ void wide_finish(const AttnParams& p, char* strip, f32x16 (&o)[2][2], const bf16x8 (&pr)[2][2],
+                                            const bf16x8 (&vf)[2][2], const float (&m)[2], const float (&l)[2], int b, int h, int qw,
+                                            int lane) {
+  const int hi = lane >> 5, lq = lane & 31;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][s2], pr[1][s2], o[1][db], 0, 0, 0);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float lt = half_swap_sum(l[qb]);
+    const float inv = 1.f / lt;
+    if (hi == 0) p.lse[(static_cast<long long>(b) * p.H + h) * p.T + qw + 32 * qb + lq] = (m[qb] + log2f(lt)) * 0.6931471805599453f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = BF16::from_f32(o[qb][db][4 * j + e] * inv);
+        *reinterpret_cast<u16x4*>(strip + (32 * qb + lq) * kOutPitch + (32 * db + 8 * j + 4 * hi) * 2) = w;
+      }
+  }
+  // a wave reads back only its own writes; the LDS serves one wave's requests in order
+  const long long o_stride = static_cast<long long>(p.H) * HD;
+  u16* out = p.o + (static_cast<long long>(b) * p.T + qw) * o_stride + static_cast<long long>(h) * HD;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = 8 * it + (lane >> 3), ch = lane & 7;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(strip + r * kOutPitch + ch * 16);
+    *reinterpret_cast<u32x4*>(out + r * o_stride + ch * 8) = v;
+  }
+}
+
+#ifdef WIDE_STAMP
+// Diagnostic build (tools/kernel_harness/attn_wide_stamps.hip): per wave, cycles spent in the six sections of a step.
+__device__ unsigned long long g_wide_stamps[1024][20];
+#define WIDE_T(var)                                                         \
+  unsigned long long var;                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                        \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+#define WIDE_ACC(i, a, b) wide_acc[i] += (b) - (a)
+#define WIDE_STAMP_ARG , unsigned long long (&wide_acc)[20]
+#define WIDE_STAMP_PASS , wide_acc
+#else
+#define WIDE_T(var)
+#define WIDE_ACC(i, a, b)
+#define WIDE_STAMP_ARG
+#define WIDE_STAMP_PASS
+#endif
+// One block of 128 queries of one (batch, head), by one wave pair (`smem` is the pair's own LDS).
+__device__ __forceinline__ void attn_fwd_wide_block(const AttnParams& p, char* smem, int bh, int qblk WIDE_STAMP_ARG) {
+  const int b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 1);
+  const int hi = lane >> 5, lq = lane & 31;
+  const int q0 = qblk * BQ, qw = q0 + wid * 64;
+  const int nb_wg = (q0 + BQ) / KB, nb_w = (qw + 64) / KB;  // key blocks of the workgroup / of this wave (>= 2)
+  const int last = nb_w - 1;
+
+  const long long head_off = static_cast<long long>(b) * p.T * p.row_stride + static_cast<long long>(h) * HD;
+  const u16* Q = p.q + head_off;
+  const char* Kb = reinterpret_cast<const char*>(p.k + head_off);
+  const char* Vb = reinterpret_cast<const char*>(p.v + head_off);
+  const long long blk_step = static_cast<long long>(KB) * p.row_stride * 2;  // bytes between consecutive key blocks
+
+  char* kring = smem;
+  char* vring = smem + kRing * kBlkBytes;
+  char* strip = smem + wid * kWideStripBytes;  // inside the rings: written after the pair's last step
+  const unsigned kring_addr = lds_address(kring), vring_addr = lds_address(vring);
+
+  // lane constants of the fragment reads (ds = 0, db = 0; see wide_load_k / wide_load_v)
+  const int koff = k_off(lq, hi);
+  int voff;
+  {
+    const int i = lane & 15, g1 = (lane >> 4) & 1, pp = i & 3, row = 4 * hi + (i >> 2);
+    voff = v2_off(row, 2 * g1 + (pp >> 1)) + ((pp & 1) << 3);
+  }
+  // This wave moves pieces wid and wid + 2 (8 rows each) of every K block and every V block: rows 16 apart have
+  // the same swizzle, so the second piece is the first at a fixed distance (added to the scalar base).
+  unsigned k_src, v_src;
+  {
+    const int r = wid * 8 + (lane >> 3), pc = lane & 7;
+    k_src = static_cast<unsigned>((static_cast<long long>(r) * p.row_stride + (pc ^ ((r >> 1) & 7)) * 8) * 2);
+    v_src = static_cast<unsigned>((static_cast<long long>(r) * p.row_stride + (pc ^ (((r >> 1) & 1) << 2)) * 8) * 2);
+  }
+  const long long piece_step = 16 * p.row_stride * 2;
+  auto request_k = [&](int j) {
+    const char* base = uniform_ptr(Kb + j * blk_step);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma_piece(base + i * piece_step, k_src, kring_addr + (j & (kRing - 1)) * kBlkBytes + (wid + 2 * i) * 1024);
+  };
+  auto request_v = [&](int j) {
+    const char* base = uniform_ptr(Vb + j * blk_step);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma_piece(base + i * piece_step, v_src, vring_addr + (j & (kRing - 1)) * kBlkBytes + (wid + 2 * i) * 1024);
+  };
+
+  // Requests are issued as if by steps -kAhead .. -1 of the loop below (step t asks for V(t + kAhead) and
+  // K(t + kAhead + 1)), after K(0); the Q loads ride behind the first three, which the first wait covers.
+  WIDE_T(tb0);
+  __syncthreads();  // the previous item's last reads of the rings and of the strip are done
+  request_k(0);
+  request_v(0);
+  request_k(1);
+  // Q fragments (B operand of the score product): lane = query 32*qb + lq, d = 16*ds + 8*hi ..
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+      qf[qb][ds] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(qw + 32 * qb + lq) * p.row_stride + 16 * ds + 8 * hi);
+#pragma unroll
+  for (int t = 1 - kAhead; t < 0; ++t) {
+    if (t + kAhead < nb_wg) request_v(t + kAhead);
+    if (t + kAhead + 1 < nb_wg) request_k(t + kAhead + 1);
+  }
+
+  f32x16 o[2][2], s[2];
+  bf16x8 pr[2][2], kf[4], vf[2][2];
+  float m[2], l[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    m[qb] = -__builtin_huge_valf();
+    l[qb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][db][e] = 0.f;
+  }
+  // Outstanding requests of this wave that a step may leave in flight: those of the kAhead - 1 steps before it.
+  auto younger = [&](int bb) {
+    const int v_hi = min(nb_wg, bb + kAhead), k_hi = min(nb_wg, bb + kAhead + 1);
+    return 2 * max(0, v_hi - (bb + 1)) + 2 * max(0, k_hi - (bb + 2));
+  };
+  auto wait_landed = [&](int bb) {  // K(bb+1) and V(bb) of this wave's pieces have landed
+    switch (younger(bb)) {
+      case 4: wait_vmem_at_most<4>(); break;
+      case 2: wait_vmem_at_most<2>(); break;
+      default: wait_vmem_at_most<0>(); break;
+    }
+  };
+  static_assert(kAhead == 2, "the wait table above lists the counts for a lead of two steps");
+  wait_landed(0);
+  __syncthreads();
+
+  const float c = p.scale_log2;
+  // rel of query block R and key block j = query - first key of the lane half; block j touches the diagonal of
+  // query block 0 from nb_w - 2 on, of query block 1 only as the last one.
+  const int rel_q0 = qw + lq - 4 * hi;
+  auto rel = [&](int r, int j) { return rel_q0 + 32 * r - 32 * j; };
+  auto k_addr = [&](int j) { return ((j & (kRing - 1)) * kBlkBytes) | koff; };
+  auto v_addr = [&](int j) { return ((j & (kRing - 1)) * kBlkBytes) + voff; };
+
+  // S(0)[0]
+  wide_load_k(kring, koff, kf);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[0][e] = 0.f;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[0][ds], s[0], 0, 0, 0);
+  wide_between<0>(s, m, l, o, 0 >= last - 1, rel(0, 0), c);
+
+  auto step_sync = [&](int bb) {  // K(bb+1) and V(bb) have landed and are visible; the blocks read in step bb-2 are free
+    WIDE_T(ta);
+    if (bb > 0) {
+      wait_landed(bb);
+      WIDE_T(tb);
+      WIDE_ACC(0, ta, tb);
+      __syncthreads();
+      WIDE_T(tc);
+      WIDE_ACC(1, tb, tc);
+    }
+    WIDE_T(td);
+    if (bb + kAhead < nb_wg) request_v(bb + kAhead);
+    if (bb + kAhead + 1 < nb_wg) request_k(bb + kAhead + 1);
+    WIDE_T(te);
+    WIDE_ACC(2, td, te);
+  };
+
+  WIDE_T(tb1);
+  WIDE_ACC(8, tb0, tb1);
+  // step 0: no output product of query block 1 yet
+  step_sync(0);
+  wide_half<0, true, false>(s, pr, kf, vf, qf, o, m, l, c, kring, vring, k_addr(1), 0);
+  wide_between<1>(s, m, l, o, 0 >= last, rel(1, 0), c);
+  wide_half<1, true, true>(s, pr, kf, vf, qf, o, m, l, c, kring, vring, 0, v_addr(0));
+  wide_between<0>(s, m, l, o, 1 >= last - 1, rel(0, 1), c);
+  WIDE_T(tb2);
+  WIDE_ACC(9, tb1, tb2);
+  for (int bb = 1; bb < last; ++bb) {
+    step_sync(bb);
+    WIDE_T(t0);
+    wide_half<0, true, true>(s, pr, kf, vf, qf, o, m, l, c, kring, vring, k_addr(bb + 1), 0);
+    WIDE_T(t1);
+    wide_between<1>(s, m, l, o, false, 0, c);  // query block 1 only meets the diagonal in the wave's last block
+    WIDE_T(t2);
+    wide_half<1, true, true>(s, pr, kf, vf, qf, o, m, l, c, kring, vring, 0, v_addr(bb));
+    WIDE_T(t3);
+    wide_between<0>(s, m, l, o, bb + 1 >= last - 1, rel(0, bb + 1), c);
+    WIDE_T(t4);
+    WIDE_ACC(3, t0, t1);
+    WIDE_ACC(4, t1, t2);
+    WIDE_ACC(5, t2, t3);
+    WIDE_ACC(6, t3, t4);
+    WIDE_ACC(7, 0, 1);
+  }
+  WIDE_T(tb3);
+  WIDE_ACC(10, tb2, tb3);
+  // the wave's last block: no further scores of query block 0
+  step_sync(last);
+  wide_half<0, true, true>(s, pr, kf, vf, qf, o, m, l, c, kring, vring, k_addr(last + 1), 0);
+  wide_between<1>(s, m, l, o, true, rel(1, last), c);
+  wide_half<1, false, true>(s, pr, kf, vf, qf, o, m, l, c, kring, vring, 0, v_addr(last));
+  WIDE_T(tb4);
+  WIDE_ACC(11, tb3, tb4);
+  for (int r = nb_w; r < nb_wg; ++r) step_sync(r);  // the other wave's remaining steps: its blocks still come through this wave's DMA
+  __syncthreads();  // nobody reads the rings any more: they become the output strips
+  WIDE_T(tb5);
+  WIDE_ACC(12, tb4, tb5);
+  wide_finish(p, strip, o, pr, vf, m, l, b, h, qw, lane);
+  WIDE_T(tb6);
+  WIDE_ACC(13, tb5, tb6);
+  WIDE_ACC(14, 0, 1);
+}
+
+// Registers: everything lives in (at most 256) architectural registers -- the score accumulators are read by the
+// vector ALU, so the matrix instructions write ordinary registers.
+__global__ __launch_bounds__(kWideThreads, 2) void attn_fwd_wide_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[kWideLdsBytes];
+  const int side = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);  // which wave pair
+#ifdef WIDE_STAMP
+  unsigned long long wide_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  WIDE_T(t_kernel0);
+  const unsigned long long rt_kernel0 = wall_clock64();
+#endif
+  const int nqb = p.T / BQ, per_head = (nqb + 1) >> 1, n_items = per_head * ((p.B * p.H) >> 1);  // an item: one block pair of TWO heads
+  for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    int pair, bh2;
+    item_of_index(idx, n_items, per_head, pair, bh2);
+    const int hi = nqb - 1 - pair;
+    for (int half = 0; half < (pair != hi ? 2 : 1); ++half)
+      attn_fwd_wide_block(p, smem + side * kWidePairLds, 2 * bh2 + side, half == 0 ? hi : pair WIDE_STAMP_PASS);
+  }
+#ifdef WIDE_STAMP
+  WIDE_T(t_kernel1);
+  wide_acc[15] = t_kernel1 - t_kernel0;
+  wide_acc[16] = wall_clock64() - rt_kernel0;  // 100 MHz
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {
+    for (int i = 0; i < 20; ++i) g_wide_stamps[blockIdx.x * 4 + (threadIdx.x >> 6)][i] = wide_acc[i];
   }
 #endif
 }
@@ -861,20 +1322,37 @@ namespace {
 // the number of work items, and a multiple of 8 so that the items a workgroup strides over all belong
 // to its own XCD's run.
 template <typename Kernel>
-int resident_per_cu(Kernel kernel) {
+int resident_per_cu(Kernel kernel, int threads = kThreads) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
   return per_cu;
 }
-unsigned persistent_grid(int per_cu, int T, int B, int H) {
+// DPA_ATTN_FWD=classic|wide forces one forward kernel (default: the wide one where it pays, see launch_attention_fwd);
+// DPA_ATTN_WIDE_PER_CU caps the wide kernel's workgroups per CU.
+int wide_forward_mode() {
+  const char* e = getenv("DPA_ATTN_FWD");
+  if (e && e[0] == 'c') return 0;
+  if (e && e[0] == 'w') return 2;
+  return 1;
+}
+int wide_per_cu() {
+  int n = resident_per_cu(attn_fwd_wide_kernel, kWideThreads);
+  const char* e = getenv("DPA_ATTN_WIDE_PER_CU");
+  if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
+  return n;
+}
+int cu_count() {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
-  const long long items = static_cast<long long>((T / BQ + 1) / 2) * B * H;
-  long long g = static_cast<long long>(cus) * per_cu;
+  return cus;
+}
+unsigned persistent_grid(int per_cu, int T, int B, int H, int heads_per_item = 1) {
+  const long long items = static_cast<long long>((T / BQ + 1) / 2) * B * H / heads_per_item;
+  long long g = static_cast<long long>(cu_count()) * per_cu;
   if (g > items) g = items;
   g = g >= 8 ? g / 8 * 8 : g;
   return static_cast<unsigned>(g < 1 ? 1 : g);
@@ -886,7 +1364,7 @@ bool attention_supported(long long T, long long head_dim, long long row_stride) 
 }
 
 void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, long long row_stride, int B, int H,
-                          int T, float softmax_scale, hipStream_t stream) {
+                          int T, float softmax_scale, hipStream_t stream, int kernel) {
   AttnParams p;
   p.q = static_cast<const u16*>(q);
   p.k = static_cast<const u16*>(k);
@@ -896,6 +1374,20 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
   p.row_stride = row_stride;
   p.B = B; p.H = H; p.T = T;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
+  // The wide kernel's workgroups take heads two at a time, so it has half as many work items; it wins (3-12 % at
+  // B32-64 x H12 x T1024, T2048, T4096) once those fill the chip, and loses below (B8: 39 vs 32 us).
+  static const int env_mode = wide_forward_mode();  // 0 never, 1 when it pays, 2 whenever possible
+  const int wide_mode = kernel == 0 ? 0 : kernel == 1 ? 2 : env_mode;
+  if (wide_mode > 0 && (static_cast<long long>(B) * H) % 2 == 0) {
+    static const int per_cu = wide_per_cu();
+    const unsigned grid = persistent_grid(per_cu, T, B, H, 2);
+    const long long items = static_cast<long long>((T / BQ + 1) / 2) * B * H / 2;
+    if (wide_mode == 2 || items >= 2LL * cu_count() * per_cu) {
+      p.per_cu = per_cu;
+      hipLaunchKernelGGL(attn_fwd_wide_kernel, dim3(grid), dim3(kWideThreads), 0, stream, p);
+      return;
+    }
+  }
   static const int fwd_per_cu = resident_per_cu(attn_fwd_kernel);
   p.per_cu = fwd_per_cu;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(persistent_grid(fwd_per_cu, T, B, H)), dim3(kThreads), 0, stream, p);

@@ -896,7 +896,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor 
 
 // ------------------------------------------------------------------ attention
 // qkv: [B, T, 3*H*64] bf16 (q | k | v along the last dimension).  Returns (o [B,T,H*64], lse [B,H,T]).
-std::tuple<Tensor, Tensor> attention_forward(Tensor qkv, int64_t n_head, double softmax_scale) {
+// kernel: "auto", "classic" (32 queries per wave, two waves per SIMD) or "wide" (64 queries per wave; B*H must be even).
+std::tuple<Tensor, Tensor> attention_forward(Tensor qkv, int64_t n_head, double softmax_scale, const std::string& kernel) {
   check_gpu(qkv, "qkv");
   TORCH_CHECK(qkv.dim() == 3 && qkv.scalar_type() == at::kBFloat16, "attention_forward: qkv must be bf16 [B, T, 3*C]");
   const int64_t B = qkv.size(0), T = qkv.size(1), C3 = qkv.size(2);
@@ -907,8 +908,11 @@ std::tuple<Tensor, Tensor> attention_forward(Tensor qkv, int64_t n_head, double 
   Tensor lse = at::empty({B, n_head, T}, qkv.options().dtype(at::kFloat));
   DevGuard guard(qkv);
   const char* base = static_cast<const char*>(qkv.data_ptr());
+  TORCH_CHECK(kernel == "auto" || kernel == "classic" || kernel == "wide", "attention_forward: kernel must be auto, classic or wide");
+  TORCH_CHECK(kernel != "wide" || (B * n_head) % 2 == 0, "attention_forward: the wide kernel takes heads two at a time, B * n_head must be even");
   kernels::launch_attention_fwd(base, base + Cd * 2, base + 2 * Cd * 2, o.data_ptr(), lse.data_ptr<float>(), C3, static_cast<int>(B),
-                                static_cast<int>(n_head), static_cast<int>(T), static_cast<float>(softmax_scale), stream_of(qkv));
+                                static_cast<int>(n_head), static_cast<int>(T), static_cast<float>(softmax_scale), stream_of(qkv),
+                                kernel == "auto" ? -1 : kernel == "wide" ? 1 : 0);
   return {o, lse};
 }
 
@@ -994,7 +998,7 @@ void init_ops(py::module_& m) {
   m.def("embedding_supported", &embedding_ok, py::arg("idx"), py::arg("wte"), py::arg("wpe"), py::arg("T"));
   m.def("embedding_forward", &embedding_forward, py::arg("idx"), py::arg("wte"), py::arg("wpe"), py::arg("T"));
   m.def("embedding_backward", &embedding_backward, py::arg("grad"), py::arg("tok_sorted"), py::arg("perm"), py::arg("T"), py::arg("V"), py::arg("P"));
-  m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("n_head"), py::arg("softmax_scale"));
+  m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("n_head"), py::arg("softmax_scale"), py::arg("kernel") = "auto");
   m.def("attention_backward", &attention_backward, py::arg("do"), py::arg("qkv"), py::arg("o"), py::arg("lse"), py::arg("n_head"),
         py::arg("softmax_scale"), py::arg("want_bias_grad") = false);
   m.def("gemm_bf16_split_k", [](int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor) {

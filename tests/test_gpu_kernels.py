@@ -527,14 +527,17 @@ def _attention_reference(qkv, H, scale):
     return (q, k, v), o, lse
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 256, 3), (1, 640, 2), (2, 1024, 12)])
-def test_flash_attention_forward_backward(B, T, H):
+@pytest.mark.parametrize("kernel", ["classic", "wide"])
+@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 256, 3), (1, 640, 2), (2, 1024, 12), (1, 128, 2), (2, 384, 5)])
+def test_flash_attention_forward_backward(B, T, H, kernel):
+    if kernel == "wide" and (B * H) % 2:
+        pytest.skip("the 64-queries-per-wave kernel takes heads two at a time")
     torch.manual_seed(B * 1000 + T + H)
     Cd = H * 64
     qkv = torch.randn(B, T, 3 * Cd, device=DEV).bfloat16()
     scale = 1.0 / math.sqrt(64)
     assert C().attention_supported(T, 64, 3 * Cd)
-    o, lse = C().attention_forward(qkv, H, scale)
+    o, lse = C().attention_forward(qkv, H, scale, kernel)
     (q, k, v), ref_o, ref_lse = _attention_reference(qkv, H, scale)
     # the row sums are taken over the bf16-rounded probabilities (the values that multiply V), by the
     # matrix pipe: the log-sum-exp carries that rounding, at most 2^-9 relative on the sum
@@ -549,7 +552,8 @@ def test_flash_attention_forward_backward(B, T, H):
     assert err <= 1e-2 * ref_g.abs().max().item() + 1e-2, err
 
 
-def test_flash_attention_large_logits_and_causality():
+@pytest.mark.parametrize("kernel", ["classic", "wide"])
+def test_flash_attention_large_logits_and_causality(kernel):
     """Scores of magnitude ~60 (softmax saturates) stay finite, and outputs at position t do not
     depend on inputs after t."""
     torch.manual_seed(7)
@@ -557,19 +561,40 @@ def test_flash_attention_large_logits_and_causality():
     Cd = H * 64
     qkv = (torch.randn(B, T, 3 * Cd, device=DEV) * 3).bfloat16()
     scale = 1.0
-    o, lse = C().attention_forward(qkv, H, scale)
+    o, lse = C().attention_forward(qkv, H, scale, kernel)
     _, ref_o, ref_lse = _attention_reference(qkv, H, scale)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     torch.testing.assert_close(lse, ref_lse, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(o.float(), ref_o, rtol=3e-2, atol=3e-2)
     qkv2 = qkv.clone()
     qkv2[:, 130:] = torch.randn_like(qkv2[:, 130:])
-    o2, _ = C().attention_forward(qkv2, H, scale)
+    o2, _ = C().attention_forward(qkv2, H, scale, kernel)
     assert torch.equal(o[:, :130], o2[:, :130])
     g = torch.zeros_like(o)
     g[:, :130] = 1
     d, _ = C().attention_backward(g, qkv, o, lse, H, scale)
     assert torch.count_nonzero(d[:, 130:].float()) == 0  # no gradient flows to later positions
+
+
+@pytest.mark.parametrize("kernel", ["classic", "wide"])
+def test_flash_attention_growing_maximum(kernel):
+    """Scores that keep growing along the keys (every block raises the running maximum by far more than the deferral
+    threshold) exercise the rescale of the partial output and row sum in every step."""
+    torch.manual_seed(11)
+    B, T, H = 2, 512, 2
+    Cd = H * 64
+    q = torch.randn(B, T, H, 64, device=DEV)
+    k = torch.randn(B, T, H, 64, device=DEV) * 0.1
+    ramp = torch.linspace(0, 6, T, device=DEV).view(1, T, 1)
+    q[..., 0] = 4.0                      # score(q, key j) ~ 4 * ramp(j) * 8 / 8: grows by ~24 over the sequence
+    k[..., 0] = ramp
+    v = torch.randn(B, T, H, 64, device=DEV)
+    qkv = torch.cat([q.reshape(B, T, Cd), k.reshape(B, T, Cd), v.reshape(B, T, Cd)], dim=2).bfloat16()
+    scale = 1.0
+    o, lse = C().attention_forward(qkv, H, scale, kernel)
+    _, ref_o, ref_lse = _attention_reference(qkv, H, scale)
+    torch.testing.assert_close(lse, ref_lse, rtol=1e-4, atol=4e-3)
+    torch.testing.assert_close(o.float(), ref_o, rtol=3e-2, atol=3e-2)
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 384, 3), (4, 1024, 12), (16, 1024, 2), (20, 1024, 1)])  # the last two: >= 512 partial rows (wide reduction kernel)

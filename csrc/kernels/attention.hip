@@ -1314,6 +1314,358 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParam
   }
 }
 
+// =====================================================================================
+// Backward on v_mfma_f32_32x32x16_bf16.  Same decomposition, rings, work items and outputs as the two kernels above;
+// what changes is the matrix instruction: a wave's 32 queries (dQ kernel) or 32 keys (dK/dV kernel) sit on the 32
+// accumulator columns, so every product of a 32 x 32 block takes 4 instructions instead of 8.  A matrix instruction
+// holds the issue port it shares with the vector ALU for ~20 cycles whatever its shape (tools/kernel_harness/
+// mfma_chain_probe.hip: the FLOPs of 8 of these next to 48 vector instructions take 460 cycles, as 16 of the 16x16x32
+// kind 592).  Built to test whether that port bounds the backward: it does not (see backward_mode() below for the
+// numbers), so these kernels are selectable (kernel = "wide", DPA_ATTN_BWD=wide) but not the default.
+// Tiles that are read both row-wise and transposed use one image (x_off): chunk ^ rot3((row >> 1) & 7) -- 16 consecutive
+// rows of one chunk cover all banks (row-wise 16-byte reads of a quarter wave), and rows r, r + 2 of a 4-row x 64-byte
+// block fall into different 64-byte halves (transposing reads of a half wave).
+// =====================================================================================
+__device__ __forceinline__ int x_swz(int row) {
+  const int p = (row >> 1) & 7;
+  return ((p & 1) << 2) | (p >> 1);
+}
+__device__ __forceinline__ int x_off(int row, int c) { return row * 128 + ((c ^ x_swz(row)) << 4); }
+__device__ __forceinline__ const u16* dma_src_x(const u16* base, long long row_stride, int piece, int lane) {
+  const int r = piece * 8 + (lane >> 3), pc = lane & 7;
+  return base + static_cast<long long>(r) * row_stride + (pc ^ x_swz(r)) * 8;
+}
+// Row fragment (A or B operand): row = 32*rblk + (lane & 31), k = 16*ds + 8*(lane >> 5) ..
+__device__ __forceinline__ bf16x8 row32_frag(const char* tile, int rblk, int ds, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + x_off(32 * rblk + (lane & 31), 2 * ds + (lane >> 5)));
+}
+// Transposed fragment (A operand X^T): row of X^T = column 32*db + (lane & 31) of the tile; the eight k-slots of lane
+// half hi are tile rows row_base + 16*s2 + 4*hi + (0..3) and + 8 + (0..3): the rows a 32x32 accumulator keeps in
+// registers 8*s2 .. 8*s2+7 of that half.
+__device__ __forceinline__ bf16x8 tr32_frag(const char* tile, int row_base, int s2, int db, int lane) {
+  const int i = lane & 15, g1 = (lane >> 4) & 1, hi = lane >> 5, pp = i & 3;
+  const int c = 2 * (2 * db + g1) + (pp >> 1), sub = (pp & 1) << 3;
+  const int r1 = row_base + 16 * s2 + 4 * hi + (i >> 2), r2 = r1 + 8;
+  using lds_ptr = __attribute__((address_space(3))) s16x4*;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + x_off(r1, c) + sub));
+  const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + x_off(r2, c) + sub));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8_of(const f32x16& a, int s2) {
+  return pack8(a[8 * s2], a[8 * s2 + 1], a[8 * s2 + 2], a[8 * s2 + 3], a[8 * s2 + 4], a[8 * s2 + 5], a[8 * s2 + 6], a[8 * s2 + 7]);
+}
+// 32 output rows x 64 d of a wave (acc[db][i]: row = lane & 31, d = 32*db + (i & 3) + 8*(i >> 2) + 4*(lane >> 5)) through
+// the wave's LDS strip, as store_rows_staged does for the 16x16 layout; `colsum` likewise.
+template <bool STREAM>
+__device__ __forceinline__ void store_rows32_staged(char* strip, const f32x16 (&acc)[2], float row_scale, u16* out, long long row_stride,
+                                                    int lane, float* colsum = nullptr) {
+  const int hi = lane >> 5, lq = lane & 31;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u16x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = BF16::from_f32(acc[db][4 * j + e] * row_scale);
+      *reinterpret_cast<u16x4*>(strip + lq * kOutPitch + (32 * db + 8 * j + 4 * hi) * 2) = w;
+    }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = 8 * it + (lane >> 3), ch = lane & 7;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(strip + r * kOutPitch + ch * 16);
+    if (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + r * row_stride + ch * 8));
+    else *reinterpret_cast<u32x4*>(out + r * row_stride + ch * 8) = v;
+  }
+  if (colsum) {
+    float cs = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) cs += BF16::to_f32(*reinterpret_cast<const u16*>(strip + r * kOutPitch + lane * 2));
+    colsum[lane] = cs;
+  }
+}
+
+// dQ: one 64-key tile for the wave's 32 queries (lane & 31 = query).
+template <bool MASK>
+__device__ __forceinline__ void dq32_tile(const char* ks, const char* vs, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], f32x16 (&dq)[2],
+                                          float lse2, float dl, int key0, int q0, int lane, float c) {
+  const int hi = lane >> 5, lq = lane & 31;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    if (MASK && key0 + 32 * kb > q0 + 31) break;  // every key of the block is in the future of every query of the wave
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[e] = 0.f;
+      dp[e] = 0.f;
+    }
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row32_frag(ks, kb, ds, lane), qf[ds], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row32_frag(vs, kb, ds, lane), dof[ds], dp, 0, 0, 0);
+    }
+    const int rel = q0 + lq - key0 - 32 * kb - 4 * hi;  // register i holds key (i & 3) + 8 * (i >> 2) of the lane half
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float pe = fast_exp2(fmaf(s[i], c, -lse2));
+      if (MASK && ((i & 3) + 8 * (i >> 2) > rel)) pe = 0.f;
+      s[i] = pe * (dp[i] - dl);  // the softmax scale is applied once, to the finished dQ rows
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 dsf = pack8_of(s, s2);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32_frag(ks, 32 * kb, s2, db, lane), dsf, dq[db], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void attn_bwd_dq32_block(const AttnBwdParams& p, char* smem, int bh, int qb, int round) {
+  const int b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int q0 = qb * BQ + wid * 32;
+
+  const long long head_off = static_cast<long long>(b) * p.T * p.row_stride + static_cast<long long>(h) * HD;
+  const u16* Q = p.q + head_off;
+  const u16* K = p.k + head_off;
+  const u16* V = p.v + head_off;
+  const long long o_stride = static_cast<long long>(p.H) * HD;
+  const u16* DO = p.d_o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
+  const u16* O = p.o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
+  const long long stat_off = (static_cast<long long>(b) * p.H + h) * p.T;
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[db][e] = 0.f;
+
+  // the same three-stage LDS-DMA ring as in attn_bwd_dq_block; both tiles in the x_off image
+  const int n_tiles = (qb * BQ + BQ) / BKV;
+  const bool moves_v = wid >= 2;
+  const int piece0 = (wid & 1) * 4;
+  const u16* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) src[i] = dma_src_x(moves_v ? V : K, p.row_stride, piece0 + i, lane);
+  const long long tile_step = static_cast<long long>(BKV) * p.row_stride;
+  const unsigned dst0 = lds_address(smem) + (moves_v ? kTileBytes : 0) + piece0 * 1024;
+  auto request = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma_16B(src[i], dst0 + stage * 2 * kTileBytes + i * 1024);
+      src[i] += tile_step;
+    }
+  };
+  __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
+  request(0);
+  if (n_tiles > 1) request(1);
+  // the wave's own rows (B operands: lane & 31 = query, d = 16*ds + 8*hi ..) and delta = sum_d dO * O
+  bf16x8 qf[4], dof[4];
+  const int qi = q0 + lq;
+  float part = 0.f;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    qf[ds] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(qi) * p.row_stride + 16 * ds + 8 * hi);
+    dof[ds] = *reinterpret_cast<const bf16x8*>(DO + static_cast<long long>(qi) * o_stride + 16 * ds + 8 * hi);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + static_cast<long long>(qi) * o_stride + 16 * ds + 8 * hi);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part = fmaf(static_cast<float>(dof[ds][j]), static_cast<float>(of[j]), part);
+  }
+  const float lse2 = p.lse[stat_off + qi] * 1.4426950408889634f;
+  const float dl = half_swap_sum(part);  // the two lane halves hold 32 d each
+  if (hi == 0) {
+    p.delta[stat_off + qi] = dl;
+    p.lse2[stat_off + qi] = lse2;
+  }
+  wait_all_vmem();
+  int stage = 0;
+  for (int jt = 0; jt < n_tiles; ++jt) {
+    take_turns(jt + round);
+    if (jt + 1 < n_tiles) wait_vmem_at_most<4>();
+    else wait_vmem_at_most<0>();
+    __syncthreads();
+    if (jt + 2 < n_tiles) request(stage == 0 ? 2 : stage - 1);
+    const char* ks = smem + stage * 2 * kTileBytes;
+    const char* vs = ks + kTileBytes;
+    const int key0 = jt * BKV;
+    if (key0 <= q0 + 31) {
+      if (key0 + BKV - 1 > q0) dq32_tile<true>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2);
+      else dq32_tile<false>(ks, vs, qf, dof, dq, lse2, dl, key0, q0, lane, p.scale_log2);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  __syncthreads();  // tile stages -> output strips
+  const long long C3 = 3LL * p.H * HD;
+  float* bq = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + q0) >> 5) * C3 + static_cast<long long>(h) * HD : nullptr;
+  store_rows32_staged<true>(smem + wid * kOutStripBytes, dq, p.scale,
+                            p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD,
+                            p.grad_row_stride, lane, bq);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq32_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
+  const int round = dispatch_round(p.per_cu_dq);
+  const int nqb = p.T / BQ, per_head = (nqb + 1) >> 1, n_items = per_head * p.B * p.H;
+  for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    int pair, bh;
+    item_of_index(idx, n_items, per_head, pair, bh);
+    const int hi = nqb - 1 - pair;
+    for (int half = 0; half < (pair != hi ? 2 : 1); ++half) attn_bwd_dq32_block(p, smem, bh, half == 0 ? hi : pair, round);
+  }
+}
+
+// dK / dV: the 32 queries qt0 .. qt0+31 (rows 32*hf .. of the stage's tiles) for the wave's 32 keys (lane & 31 = key).
+template <bool MASK>
+__device__ __forceinline__ void dkdv32_tile(const char* qs_, const char* dos_, const bf16x8 (&kfB)[4], const bf16x8 (&vfB)[4], f32x16 (&dk)[2],
+                                            f32x16 (&dv)[2], const char* stats, int hf, int qt0, int k0w, int lane, float c) {
+  const int hi = lane >> 5, lk = lane & 31;
+  f32x16 s, dp;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    s[e] = 0.f;
+    dp[e] = 0.f;
+  }
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row32_frag(qs_, hf, ds, lane), kfB[ds], s, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row32_frag(dos_, hf, ds, lane), vfB[ds], dp, 0, 0, 0);
+  }
+  // register i: query = qt0 + (i & 3) + 8 * (i >> 2) + 4 * hi; its statistics come four queries at a time
+  const int rel = k0w + lk - qt0 - 4 * hi;  // masked (the key is in the query's future) when (i & 3) + 8 * (i >> 2) < rel
+  f32x16 pv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 l2 = *reinterpret_cast<const f32x4*>(stats + (32 * hf + 8 * j + 4 * hi) * 4);
+    const f32x4 dl = *reinterpret_cast<const f32x4*>(stats + BQT * 4 + (32 * hf + 8 * j + 4 * hi) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = fast_exp2(fmaf(s[4 * j + e], c, -l2[e]));
+      if (MASK && (8 * j + e < rel)) pe = 0.f;
+      pv[4 * j + e] = pe;
+      s[4 * j + e] = pe * (dp[4 * j + e] - dl[e]);  // the softmax scale is applied once, to the finished dK rows
+    }
+  }
+  // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS   (contraction over the 32 queries)
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const bf16x8 pB = pack8_of(pv, s2), dsB = pack8_of(s, s2);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32_frag(dos_, 32 * hf, s2, db, lane), pB, dv[db], 0, 0, 0);
+      dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32_frag(qs_, 32 * hf, s2, db, lane), dsB, dk[db], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void attn_bwd_dkdv32_block(const AttnBwdParams& p, char* smem, int bh, int jb, int round) {
+  const int b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hi = lane >> 5, lk = lane & 31;
+  const int k0w = jb * BQ + wid * 32;  // this wave's 32 keys
+
+  const long long head_off = static_cast<long long>(b) * p.T * p.row_stride + static_cast<long long>(h) * HD;
+  const u16* Q = p.q + head_off;
+  const u16* K = p.k + head_off;
+  const u16* V = p.v + head_off;
+  const long long o_stride = static_cast<long long>(p.H) * HD;
+  const u16* DO = p.d_o + static_cast<long long>(b) * p.T * o_stride + static_cast<long long>(h) * HD;
+  const long long stat_off = (static_cast<long long>(b) * p.H + h) * p.T;
+  const float* lse2 = p.lse2 + stat_off;
+  const float* delta = p.delta + stat_off;
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      dk[db][e] = 0.f;
+      dv[db][e] = 0.f;
+    }
+
+  // the same three-stage ring of Q / dO tiles (64 queries) and statistics as in attn_bwd_dkdv_block; tiles in the x_off image
+  const int first_qt = (jb * BQ) / BQT, n_qt = p.T / BQT;
+  const bool moves_do = wid >= 2, moves_stat = (wid & 1) == 0;
+  const int piece0 = (wid & 1) * 4;
+  const long long src_stride = moves_do ? o_stride : p.row_stride;
+  const u16* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    src[i] = dma_src_x((moves_do ? DO : Q) + static_cast<long long>(first_qt) * BQT * src_stride, src_stride, piece0 + i, lane);
+  const float* stat_src = (moves_do ? delta : lse2) + first_qt * BQT + lane;
+  const long long tile_step = static_cast<long long>(BQT) * src_stride;
+  const unsigned smem_addr = lds_address(smem);
+  const unsigned dst0 = smem_addr + (moves_do ? kQTileBytes : 0) + piece0 * 1024;
+  const unsigned stat_dst0 = smem_addr + 2 * kQTileBytes + (moves_do ? BQT * 4 : 0);
+  auto request = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma_16B(src[i], dst0 + stage * kQStageBytes + i * 1024);
+      src[i] += tile_step;
+    }
+    if (moves_stat) {
+      dma_4B(stat_src, stat_dst0 + stage * kQStageBytes);
+      stat_src += BQT;
+    }
+  };
+  const int n_iter = n_qt - first_qt;
+  __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
+  request(0);
+  if (n_iter > 1) request(1);
+  // K / V fragments as B operands (lane & 31 = key, d = 16*ds + 8*hi ..), resident for the whole block
+  bf16x8 kfB[4], vfB[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    const long long row = k0w + lk;
+    kfB[ds] = *reinterpret_cast<const bf16x8*>(K + row * p.row_stride + 16 * ds + 8 * hi);
+    vfB[ds] = *reinterpret_cast<const bf16x8*>(V + row * p.row_stride + 16 * ds + 8 * hi);
+  }
+  wait_all_vmem();
+  int stage = 0;
+  for (int it = 0; it < n_iter; ++it) {
+    take_turns(it + round);
+    if (it + 1 < n_iter) {  // leave the next stage's requests in flight: 5 per wave with statistics, else 4
+      if (moves_stat) wait_vmem_at_most<5>();
+      else wait_vmem_at_most<4>();
+    } else {
+      wait_vmem_at_most<0>();
+    }
+    __syncthreads();
+    if (it + 2 < n_iter) request(stage == 0 ? 2 : stage - 1);
+    const char* qs_ = smem + stage * kQStageBytes;
+    const char* dos_ = qs_ + kQTileBytes;
+    const char* stats = qs_ + 2 * kQTileBytes;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int qt0 = (first_qt + it) * BQT + 32 * hf;
+      if (qt0 + 31 >= k0w) {  // otherwise every query of the half precedes all of this wave's keys
+        if (qt0 < k0w + 31) dkdv32_tile<true>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2);
+        else dkdv32_tile<false>(qs_, dos_, kfB, vfB, dk, dv, stats, hf, qt0, k0w, lane, p.scale_log2);
+      }
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  __syncthreads();  // tile stages -> output strips
+  const long long out_off = (static_cast<long long>(b) * p.T + k0w) * p.grad_row_stride + static_cast<long long>(h) * HD;
+  const long long C3 = 3LL * p.H * HD;
+  float* bk = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + k0w) >> 5) * C3 + (p.H + h) * static_cast<long long>(HD) : nullptr;
+  float* bvp = bk ? bk + static_cast<long long>(p.H) * HD : nullptr;
+  store_rows32_staged<true>(smem + wid * kOutStripBytes, dk, p.scale, p.dk + out_off, p.grad_row_stride, lane, bk);
+  store_rows32_staged<true>(smem + wid * kOutStripBytes, dv, 1.f, p.dv + out_off, p.grad_row_stride, lane, bvp);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv32_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[3 * kQStageBytes];  // [3 stages][Q | dO | lse2 | delta]
+  const int round = dispatch_round(p.per_cu_dkdv);
+  const int nkb = p.T / BQ, per_head = (nkb + 1) >> 1, n_items = per_head * p.B * p.H;
+  for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    int pair, bh;
+    item_of_index(idx, n_items, per_head, pair, bh);
+    const int lo = nkb - 1 - pair;
+    for (int half = 0; half < (pair != lo ? 2 : 1); ++half) attn_bwd_dkdv32_block(p, smem, bh, half == 0 ? pair : lo, round);
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -1334,6 +1686,14 @@ int wide_forward_mode() {
   if (e && e[0] == 'c') return 0;
   if (e && e[0] == 'w') return 2;
   return 1;
+}
+// DPA_ATTN_BWD=classic|wide forces the backward kernels on 16x16x32 / 32x32x16 matrix instructions.  Default: the former --
+// measured on the same boxes the 32x32x16 pair is 3-6 % slower alone (545 vs 515 us at B64 H12 T1024) and 0.3 % slower
+// inside the GPT-2 step, although it issues half as many matrix instructions: these kernels wait on their dependent
+// chains (fragment reads -> products -> exponentials -> products), not on the issue port.
+int backward_mode() {
+  const char* e = getenv("DPA_ATTN_BWD");
+  return (e && e[0] == 'w') ? 1 : 0;
 }
 int wide_per_cu() {
   int n = resident_per_cu(attn_fwd_wide_kernel, kWideThreads);
@@ -1395,7 +1755,7 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
 
 void launch_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                           void* dq, void* dk, void* dv, long long row_stride, long long grad_row_stride, int B, int H, int T,
-                          float softmax_scale, float* bias_partial, hipStream_t stream) {
+                          float softmax_scale, float* bias_partial, hipStream_t stream, int kernel) {
   AttnBwdParams p;
   p.o = static_cast<const u16*>(o);
   p.q = static_cast<const u16*>(q);
@@ -1415,6 +1775,16 @@ void launch_attention_bwd(const void* q, const void* k, const void* v, const voi
   p.scale = softmax_scale;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
   // dQ first: it also produces delta, which the dK/dV kernel consumes
+  static const int env_mode = backward_mode();
+  const bool wide = kernel < 0 ? env_mode != 0 : kernel == 1;
+  if (wide) {  // the kernels on 32x32x16 matrix instructions
+    static const int dq_per_cu = resident_per_cu(attn_bwd_dq32_kernel), dkdv_per_cu = resident_per_cu(attn_bwd_dkdv32_kernel);
+    p.per_cu_dq = dq_per_cu;
+    p.per_cu_dkdv = dkdv_per_cu;
+    hipLaunchKernelGGL(attn_bwd_dq32_kernel, dim3(persistent_grid(dq_per_cu, T, B, H)), dim3(kThreads), 0, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv32_kernel, dim3(persistent_grid(dkdv_per_cu, T, B, H)), dim3(kThreads), 0, stream, p);
+    return;
+  }
   static const int dq_per_cu = resident_per_cu(attn_bwd_dq_kernel), dkdv_per_cu = resident_per_cu(attn_bwd_dkdv_kernel);
   p.per_cu_dq = dq_per_cu;
   p.per_cu_dkdv = dkdv_per_cu;

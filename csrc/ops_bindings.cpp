@@ -918,7 +918,10 @@ std::tuple<Tensor, Tensor> attention_forward(Tensor qkv, int64_t n_head, double 
 
 // Returns (dqkv [B, T, 3*C], dbias [3*C] or undefined) given the forward's inputs / outputs and do [B, T, C].
 // want_bias_grad: the kernels also emit the column sums of dqkv (gradient of the projection's bias).
-std::tuple<Tensor, Tensor> attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t n_head, double softmax_scale, bool want_bias_grad) {
+// kernel: "auto", "classic" (16x16x32 matrix instructions) or "wide" (32x32x16).
+std::tuple<Tensor, Tensor> attention_backward(Tensor d_o, Tensor qkv, Tensor o, Tensor lse, int64_t n_head, double softmax_scale, bool want_bias_grad,
+                                              const std::string& kernel) {
+  TORCH_CHECK(kernel == "auto" || kernel == "classic" || kernel == "wide", "attention_backward: kernel must be auto, classic or wide");
   check_gpu(d_o, "do");
   check_gpu(qkv, "qkv");
   check_gpu(o, "o");
@@ -943,7 +946,8 @@ std::tuple<Tensor, Tensor> attention_backward(Tensor d_o, Tensor qkv, Tensor o, 
   char* gbase = static_cast<char*>(dqkv.data_ptr());
   kernels::launch_attention_bwd(base, base + Cd * 2, base + 2 * Cd * 2, o.data_ptr(), d_o.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(),
                                 gbase, gbase + Cd * 2, gbase + 2 * Cd * 2, C3, C3, static_cast<int>(B), static_cast<int>(n_head),
-                                static_cast<int>(T), static_cast<float>(softmax_scale), want_bias_grad ? partial.data_ptr<float>() : nullptr, s);
+                                static_cast<int>(T), static_cast<float>(softmax_scale), want_bias_grad ? partial.data_ptr<float>() : nullptr, s,
+                                kernel == "auto" ? -1 : kernel == "wide" ? 1 : 0);
   if (want_bias_grad) kernels::launch_reduce_partials(partial.data_ptr<float>(), dbias.data_ptr(), C3, static_cast<int>(B * T / 32), kernels::kBF16, s);
   return {dqkv, dbias};
 }
@@ -1000,7 +1004,7 @@ void init_ops(py::module_& m) {
   m.def("embedding_backward", &embedding_backward, py::arg("grad"), py::arg("tok_sorted"), py::arg("perm"), py::arg("T"), py::arg("V"), py::arg("P"));
   m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("n_head"), py::arg("softmax_scale"), py::arg("kernel") = "auto");
   m.def("attention_backward", &attention_backward, py::arg("do"), py::arg("qkv"), py::arg("o"), py::arg("lse"), py::arg("n_head"),
-        py::arg("softmax_scale"), py::arg("want_bias_grad") = false);
+        py::arg("softmax_scale"), py::arg("want_bias_grad") = false, py::arg("kernel") = "auto");
   m.def("gemm_bf16_split_k", [](int64_t M, int64_t N, int64_t K, bool a_kmajor, bool b_kmajor) {
     kernels::GemmArgs a{};
     a.M = M; a.N = N; a.K = K;

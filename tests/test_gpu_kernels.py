@@ -544,12 +544,13 @@ def test_flash_attention_forward_backward(B, T, H, kernel):
     torch.testing.assert_close(lse, ref_lse, rtol=0, atol=4e-3)
     torch.testing.assert_close(o.float(), ref_o, rtol=2e-2, atol=2e-2)
     go = torch.randn_like(o)
-    dqkv, _ = C().attention_backward(go, qkv, o, lse, H, scale)
     ref_o.backward(go.float())
     ref_g = torch.cat([t.grad.transpose(1, 2).reshape(B, T, Cd) for t in (q, k, v)], dim=2)
-    # bf16 P / dS operands and bf16 outputs: error scales with the gradient magnitude
-    err = (dqkv.float() - ref_g).abs().max().item()
-    assert err <= 1e-2 * ref_g.abs().max().item() + 1e-2, err
+    for bwd_kernel in ("classic", "wide"):  # 16x16x32 / 32x32x16 matrix instructions
+        dqkv, _ = C().attention_backward(go, qkv, o, lse, H, scale, False, bwd_kernel)
+        # bf16 P / dS operands and bf16 outputs: error scales with the gradient magnitude
+        err = (dqkv.float() - ref_g).abs().max().item()
+        assert err <= 1e-2 * ref_g.abs().max().item() + 1e-2, (bwd_kernel, err)
 
 
 @pytest.mark.parametrize("kernel", ["classic", "wide"])
@@ -572,8 +573,9 @@ def test_flash_attention_large_logits_and_causality(kernel):
     assert torch.equal(o[:, :130], o2[:, :130])
     g = torch.zeros_like(o)
     g[:, :130] = 1
-    d, _ = C().attention_backward(g, qkv, o, lse, H, scale)
-    assert torch.count_nonzero(d[:, 130:].float()) == 0  # no gradient flows to later positions
+    for bwd_kernel in ("classic", "wide"):
+        d, _ = C().attention_backward(g, qkv, o, lse, H, scale, False, bwd_kernel)
+        assert torch.count_nonzero(d[:, 130:].float()) == 0  # no gradient flows to later positions
 
 
 @pytest.mark.parametrize("kernel", ["classic", "wide"])
@@ -597,8 +599,9 @@ def test_flash_attention_growing_maximum(kernel):
     torch.testing.assert_close(o.float(), ref_o, rtol=3e-2, atol=3e-2)
 
 
+@pytest.mark.parametrize("kernel", ["classic", "wide"])
 @pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 384, 3), (4, 1024, 12), (16, 1024, 2), (20, 1024, 1)])  # the last two: >= 512 partial rows (wide reduction kernel)
-def test_attention_backward_bias_gradient(B, T, H):
+def test_attention_backward_bias_gradient(B, T, H, kernel):
     """The column sums the backward kernels emit equal the sum over positions of the dqkv they wrote."""
     torch.manual_seed(T + H)
     Cd = H * 64
@@ -606,8 +609,8 @@ def test_attention_backward_bias_gradient(B, T, H):
     scale = 1.0 / math.sqrt(64)
     o, lse = C().attention_forward(qkv, H, scale)
     go = torch.randn_like(o)
-    dqkv, db = C().attention_backward(go, qkv, o, lse, H, scale, True)
-    plain, none = C().attention_backward(go, qkv, o, lse, H, scale)
+    dqkv, db = C().attention_backward(go, qkv, o, lse, H, scale, True, kernel)
+    plain, none = C().attention_backward(go, qkv, o, lse, H, scale, False, kernel)
     assert none is None and torch.equal(dqkv, plain)
     ref = dqkv.float().sum((0, 1))
     assert db.shape == (3 * Cd,) and db.dtype == torch.bfloat16

@@ -1735,14 +1735,16 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
   p.B = B; p.H = H; p.T = T;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
   // The wide kernel's workgroups take heads two at a time, so it has half as many work items; it wins (3-12 % at
-  // B32-64 x H12 x T1024, T2048, T4096) once those fill the chip, and loses below (B8: 39 vs 32 us).
+  // B32-64 x H12 x T1024, B16 x H16 x T2048, B4 x H16 x T4096) once those fill its grid and the rows are long, ties
+  // around that point (B22-24 x H12 x T1024, B96 x H12 x T512) and loses below (B8 x H12 x T1024: 39 vs 32 us,
+  // B2 x H16 x T4096: 129 vs 107 us, B48 x H12 x T512: 55 vs 52 us).
   static const int env_mode = wide_forward_mode();  // 0 never, 1 when it pays, 2 whenever possible
   const int wide_mode = kernel == 0 ? 0 : kernel == 1 ? 2 : env_mode;
   if (wide_mode > 0 && (static_cast<long long>(B) * H) % 2 == 0) {
     static const int per_cu = wide_per_cu();
     const unsigned grid = persistent_grid(per_cu, T, B, H, 2);
     const long long items = static_cast<long long>((T / BQ + 1) / 2) * B * H / 2;
-    if (wide_mode == 2 || items >= 2LL * cu_count() * per_cu) {
+    if (wide_mode == 2 || (items >= static_cast<long long>(cu_count()) * per_cu && T >= 1024)) {
       p.per_cu = per_cu;
       hipLaunchKernelGGL(attn_fwd_wide_kernel, dim3(grid), dim3(kWideThreads), 0, stream, p);
       return;

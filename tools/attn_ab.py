@@ -2,6 +2,8 @@
 (the kernel is chosen once per process by DPA_ATTN_FWD)."""
 import os, subprocess, sys
 shapes = [(64, 1024, 12), (32, 1024, 12), (8, 1024, 12), (16, 2048, 16), (4, 4096, 16), (96, 512, 12)]
+if len(sys.argv) > 1 and sys.argv[1] == "threshold":  # where does the second kernel start to pay?  (work items = pairs of 128-query blocks of two heads)
+    shapes = [(12, 1024, 12), (16, 1024, 12), (22, 1024, 12), (24, 1024, 12), (2, 4096, 16), (4, 2048, 16), (6, 2048, 16), (24, 512, 12), (48, 512, 12)]
 code = r'''
 import sys, math, torch
 from distributed_pytorch_amd import _ext

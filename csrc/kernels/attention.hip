@@ -24,6 +24,8 @@
 // queries (4 waves x 32) of one (batch, head) and walks the key tiles (64 keys) up to the
 // diagonal; tiles are double-buffered in LDS with the loads of tile j+1 in flight during the
 // math of tile j; workgroups with the most tiles are launched first.
+// (That is the first forward kernel and the default backward pair.  Further down: a second forward kernel with 64
+// queries per wave on 32x32x16 matrix instructions, and a selectable backward pair on the same instruction.)
 #include <cstdlib>
 
 #include "device_utils.h"
@@ -475,11 +477,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
 }
 
 // =====================================================================================
-// Forward, one wave per SIMD ("wide" variant, used when it is resident -- see launch_attention_fwd).
+// Forward, 64 queries per wave on 32x32x16 matrix instructions ("wide" variant; launch_attention_fwd chooses
+// between the two forward kernels by shape).
 //
-// The kernel above keeps two waves per SIMD and lets the hardware overlap one wave's matrix work with the
-// other's softmax; measured, a SIMD then spends ~1460 cycles per 2048 (query, key) pairs although the
-// matrix pipe needs 576 and the vector ALU ~640.  Here ONE wave owns 64 queries = two query blocks of 32
+// The kernel above leaves all overlap of matrix work and softmax to the hardware's switching between its two
+// waves per SIMD; measured, a SIMD then spends ~1460 cycles per 2048 (query, key) pairs although the
+// matrix pipe needs 576 and the vector ALU ~640.  Here a wave owns 64 queries = two query blocks of 32
 // (the accumulator column = lane of v_mfma_f32_32x32x16_bf16) and overlaps the stages itself: the two query
 // blocks run half a step out of phase, so that each half-step pairs the softmax of one query block (vector
 // ALU) with the matrix work of the other, and the two never depend on each other:
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(AttnParams p) {
 // consumed, so in the rare case it fires only the output accumulators and the row sum are rescaled.
 // Row sums: v_dot2c_f32_bf16 of the packed bf16 probability pairs with (1, 1): 16 instructions per block and
 // wave instead of 32 additions, and exactly the rounded values that multiply V.
-// A workgroup is 4 waves = one per SIMD (the hardware spreads the waves of ONE workgroup over the SIMDs; two
+// A workgroup is 4 waves, one on each SIMD (the hardware spreads the waves of ONE workgroup over the SIMDs; two
 // 2-wave workgroups per CU were measured to leave a SIMD empty and another with two waves on 93 % of the CUs).
 // Its two wave pairs are independent: each works on 128 queries of its own head -- the same query blocks of two
 // neighbouring heads, so both pairs take the same number of steps and can share the workgroup barrier -- with

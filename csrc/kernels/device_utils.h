@@ -67,7 +67,7 @@ __device__ __forceinline__ void load_as_f32(const typename TR::T* p, float (&out
   }
 }
 
-template <typename TR, int N>
+template <typename TR, int N, bool STREAM = false>
 __device__ __forceinline__ void store_from_f32(typename TR::T* p, const float (&in)[N]) {
   static_assert(N % TR::kVec == 0, "N must be a multiple of the 16-byte vector width");
   if constexpr (TR::kVec == 4) {
@@ -76,7 +76,8 @@ __device__ __forceinline__ void store_from_f32(typename TR::T* p, const float (&
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = in[4 * i + j];
-      *reinterpret_cast<f32x4*>(p + 4 * i) = v;
+      if (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p + 4 * i));
+      else *reinterpret_cast<f32x4*>(p + 4 * i) = v;
     }
   } else {
 #pragma unroll
@@ -84,7 +85,8 @@ __device__ __forceinline__ void store_from_f32(typename TR::T* p, const float (&
       u16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = TR::from_f32(in[8 * i + j]);
-      *reinterpret_cast<u16x8*>(p + 8 * i) = v;
+      if (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(p + 8 * i));
+      else *reinterpret_cast<u16x8*>(p + 8 * i) = v;
     }
   }
 }
@@ -113,6 +115,11 @@ template <typename TR, int V>
 __device__ __forceinline__ raw_t<TR, V> load_raw(const typename TR::T* p) {
   return *reinterpret_cast<const raw_t<TR, V>*>(p);
 }
+// Streaming variants: data that this kernel touches once and nobody reads again soon (non-temporal hint).
+template <typename TR, int V>
+__device__ __forceinline__ raw_t<TR, V> load_raw_stream(const typename TR::T* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const raw_t<TR, V>*>(p));
+}
 template <typename TR, int V>
 __device__ __forceinline__ raw_t<TR, V> zero_raw() {
   raw_t<TR, V> r;
@@ -130,7 +137,7 @@ __device__ __forceinline__ void raw_to_f32(const raw_t<TR, V>& r, float (&out)[V
     for (int j = 0; j < V; ++j) out[j] = TR::to_f32(static_cast<u16>(j & 1 ? r[j >> 1] >> 16 : r[j >> 1] & 0xffffu));
   }
 }
-template <typename TR, int V>
+template <typename TR, int V, bool STREAM = false>
 __device__ __forceinline__ void store_raw_from_f32(typename TR::T* p, const float (&in)[V]) {
   raw_t<TR, V> r;
   if constexpr (sizeof(typename TR::T) == 4) {
@@ -141,7 +148,8 @@ __device__ __forceinline__ void store_raw_from_f32(typename TR::T* p, const floa
     for (int j = 0; j < V / 2; ++j)
       r[j] = static_cast<unsigned>(TR::from_f32(in[2 * j])) | (static_cast<unsigned>(TR::from_f32(in[2 * j + 1])) << 16);
   }
-  *reinterpret_cast<raw_t<TR, V>*>(p) = r;
+  if (STREAM) __builtin_nontemporal_store(r, reinterpret_cast<raw_t<TR, V>*>(p));
+  else *reinterpret_cast<raw_t<TR, V>*>(p) = r;
 }
 
 // Stops the compiler from expanding a loop-invariant packed vector to fp32 outside the loop (which

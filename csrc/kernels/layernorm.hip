@@ -19,6 +19,14 @@ namespace dpa {
 namespace kernels {
 
 namespace {
+#ifndef LN_STREAM_STORES
+#define LN_STREAM_STORES 1
+#endif
+#ifndef LN_STREAM_LOADS
+#define LN_STREAM_LOADS 1
+#endif
+constexpr bool kStream = LN_STREAM_STORES != 0, kStreamLoads = LN_STREAM_LOADS != 0;
+
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
@@ -65,8 +73,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
     for (int i = 0; i < MAXV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        nx[i] = load_raw<TR, V>(x + r * cols + vi * V);
-        if (res) nr[i] = load_raw<TR, V>(res + r * cols + vi * V);
+        nx[i] = kStreamLoads ? load_raw_stream<TR, V>(x + r * cols + vi * V) : load_raw<TR, V>(x + r * cols + vi * V);
+        if (res) nr[i] = kStreamLoads ? load_raw_stream<TR, V>(res + r * cols + vi * V) : load_raw<TR, V>(res + r * cols + vi * V);
       }
     }
   };
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
           }
 #pragma unroll
           for (int j = 0; j < V; ++j) v[i][j] = TR::to_f32(TR::from_f32(v[i][j] + r[j]));
-          store_raw_from_f32<TR, V>(sum_out + row * cols + vi * V, v[i]);
+          store_raw_from_f32<TR, V, kStream>(sum_out + row * cols + vi * V, v[i]);
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) s += v[i][j];
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const typename 
         raw_to_f32<TR, V>(bet[i], b);
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-        store_raw_from_f32<TR, V>(yr + vi * V, o);
+        store_raw_from_f32<TR, V, kStream>(yr + vi * V, o);
       }
     }
   }
@@ -179,8 +187,8 @@ __global__ __launch_bounds__(kThreads, V* MAXV <= 12 ? 4 : (V * MAXV <= 16 ? 3 :
     for (int i = 0; i < MAXV; ++i) {
       const int vi = lane + 64 * i;
       if (vi < nvec) {
-        nx[i] = load_raw<TR, V>(x + r * cols + vi * V);
-        ng[i] = load_raw<TR, V>(dy + r * cols + vi * V);
+        nx[i] = kStreamLoads ? load_raw_stream<TR, V>(x + r * cols + vi * V) : load_raw<TR, V>(x + r * cols + vi * V);
+        ng[i] = kStreamLoads ? load_raw_stream<TR, V>(dy + r * cols + vi * V) : load_raw<TR, V>(dy + r * cols + vi * V);
       }
     }
   };
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(kThreads, V* MAXV <= 12 ? 4 : (V * MAXV <= 16 ? 3 :
     if (dres) {
 #pragma unroll
       for (int i = 0; i < MAXV; ++i)
-        if (lane + 64 * i < nvec) cr[i] = load_raw<TR, V>(dres + row * cols + (lane + 64 * i) * V);
+        if (lane + 64 * i < nvec) cr[i] = kStreamLoads ? load_raw_stream<TR, V>(dres + row * cols + (lane + 64 * i) * V) : load_raw<TR, V>(dres + row * cols + (lane + 64 * i) * V);
     }
     // The row stays packed across the two reductions and is expanded a second time afterwards:
     // 3 VALU operations per element are cheaper than the registers fp32 copies would hold.
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(kThreads, V* MAXV <= 12 ? 4 : (V * MAXV <= 16 ? 3 :
 #pragma unroll
           for (int j = 0; j < V; ++j) ds[i][j] += o[j];
         }
-        store_raw_from_f32<TR, V>(dx + row * cols + vi * V, o);
+        store_raw_from_f32<TR, V, kStream>(dx + row * cols + vi * V, o);
       }
     }
   }

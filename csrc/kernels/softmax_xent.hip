@@ -21,6 +21,11 @@ namespace dpa {
 namespace kernels {
 
 namespace {
+#ifndef XENT_STREAM
+#define XENT_STREAM 1
+#endif
+constexpr bool kXentStream = XENT_STREAM != 0;
+
 
 constexpr float kNegInf = -__builtin_huge_valf();
 
@@ -252,7 +257,10 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void xent_fused_resident_ke
 #pragma unroll
   for (int q = 0; q < KEEP; ++q) {
     const int k = threadIdx.x + q * THREADS;
-    if (k < nvec) kept[q] = *reinterpret_cast<const raw16*>(row_bytes + 16u * static_cast<unsigned>(k));  // uniform base + 32-bit offset
+    if (k < nvec) {  // uniform base + 32-bit offset; read once
+      if (kXentStream) kept[q] = __builtin_nontemporal_load(reinterpret_cast<const raw16*>(row_bytes + 16u * static_cast<unsigned>(k)));
+      else kept[q] = *reinterpret_cast<const raw16*>(row_bytes + 16u * static_cast<unsigned>(k));
+    }
   }
   auto element = [](const raw16& v, int j) { return TR::to_f32(static_cast<u16>(v[j >> 1] >> (16 * (j & 1)))); };
 
@@ -351,10 +359,10 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void xent_fused_resident_ke
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         d[j] = j < nval ? (__expf(element(kept[q], j) - shift) - ((k == tvec && j == tsub) ? 1.f : 0.f)) * g : 0.f;
-      store_from_f32<TR, 8>(reinterpret_cast<typename TR::T*>(row_bytes + 16u * static_cast<unsigned>(k)), d);
+      store_from_f32<TR, 8, kXentStream>(reinterpret_cast<typename TR::T*>(row_bytes + 16u * static_cast<unsigned>(k)), d);
     } else if (k < nvec_ld) {
       const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      store_from_f32<TR, 8>(reinterpret_cast<typename TR::T*>(row_bytes + 16u * static_cast<unsigned>(k)), z);
+      store_from_f32<TR, 8, kXentStream>(reinterpret_cast<typename TR::T*>(row_bytes + 16u * static_cast<unsigned>(k)), z);
     }
     __builtin_amdgcn_sched_barrier(0);
   }

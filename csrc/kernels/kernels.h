@@ -218,6 +218,9 @@ void launch_layernorm_fwd(const void* x, const void* res, const void* res_bias, 
                           const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                           long long rows, long long cols, float eps, int dtype, hipStream_t stream);
 long long layernorm_bwd_workspace(long long rows, long long cols);
+// Any row width up to 8192 columns: rows of whole 16-byte vectors that fit a wave's registers take the wave-per-row
+// kernels, everything else a workgroup-per-row pair.
+bool layernorm_supported(long long cols);
 // dx = LN'(dy) (+ dres when given: the gradient reaching the normalised tensor by another path).
 // dsum != nullptr: also the column sums of dx (gradient of res_bias); needs cols <= 1365.
 void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const void* gamma,

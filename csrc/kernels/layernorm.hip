@@ -329,6 +329,117 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_reduce_kernel(const fl
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Rows a wave cannot keep in registers (more than 64 * 16 bytes * 8 (forward) / * 4 (backward)), or whose width is
+// not a multiple of the 16-byte vector: one workgroup per row, element-wise coalesced accesses, the row read again
+// from the caches for the second and third pass.  Same arithmetic, in the same order per element, as the kernels
+// above; dgamma / dbeta accumulate in the registers of the thread that owns the column (kRowCols per thread) and
+// leave as one partial row per workgroup for layernorm_bwd_reduce_kernel.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kRowCols = 32;                               // columns per thread the backward can accumulate
+constexpr long long kRowMaxCols = kRowCols * kThreads;     // 8192
+
+template <typename TR>
+__global__ __launch_bounds__(kThreads) void layernorm_fwd_row_kernel(const typename TR::T* __restrict__ x, const typename TR::T* __restrict__ res,
+                                                                     const typename TR::T* __restrict__ res_bias,
+                                                                     typename TR::T* __restrict__ sum_out, const typename TR::T* __restrict__ gamma,
+                                                                     const typename TR::T* __restrict__ beta, typename TR::T* __restrict__ y,
+                                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, long long rows,
+                                                                     int cols, float eps) {
+  __shared__ float scratch[kWaves];
+  const float inv_n = 1.f / static_cast<float>(cols);
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const typename TR::T* xr = x + row * cols;
+    const typename TR::T* rr = res ? res + row * cols : nullptr;
+    typename TR::T* sr = res ? sum_out + row * cols : nullptr;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += kThreads) {
+      float v = TR::to_f32(xr[c]);
+      if (res) {
+        float r = TR::to_f32(rr[c]);
+        if (res_bias) r = TR::to_f32(TR::from_f32(r + TR::to_f32(res_bias[c])));
+        const typename TR::T sv = TR::from_f32(v + r);
+        sr[c] = sv;  // read back below by the same thread
+        v = TR::to_f32(sv);
+      }
+      s += v;
+    }
+    const float mean = block_sum<kWaves>(s, scratch) * inv_n;
+    const typename TR::T* vr = res ? sr : xr;
+    float sq = 0.f;
+    for (int c = threadIdx.x; c < cols; c += kThreads) {
+      const float d = TR::to_f32(vr[c]) - mean;
+      sq += d * d;
+    }
+    const float rstd = rsqrtf(block_sum<kWaves>(sq, scratch) * inv_n + eps);
+    if (threadIdx.x == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    typename TR::T* yr = y + row * cols;
+    for (int c = threadIdx.x; c < cols; c += kThreads)
+      yr[c] = TR::from_f32((TR::to_f32(vr[c]) - mean) * rstd * TR::to_f32(gamma[c]) + TR::to_f32(beta[c]));
+  }
+}
+
+template <typename TR, bool DSUM>
+__global__ __launch_bounds__(kThreads) void layernorm_bwd_row_kernel(const typename TR::T* __restrict__ dy, const typename TR::T* __restrict__ x,
+                                                                     const typename TR::T* __restrict__ dres,
+                                                                     const typename TR::T* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                                     const float* __restrict__ rstd_in, typename TR::T* __restrict__ dx,
+                                                                     float* __restrict__ partial, long long rows, int cols) {
+  __shared__ float scratch[kWaves];
+  constexpr int NACC = DSUM ? 3 : 2;
+  const float inv_n = 1.f / static_cast<float>(cols);
+  float dg[kRowCols], db[kRowCols], ds[DSUM ? kRowCols : 1];
+#pragma unroll
+  for (int k = 0; k < kRowCols; ++k) {
+    dg[k] = db[k] = 0.f;
+    if (DSUM) ds[k] = 0.f;
+  }
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const typename TR::T* gr = dy + row * cols;
+    const typename TR::T* xr = x + row * cols;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kRowCols; ++k) {
+      const int c = threadIdx.x + k * kThreads;
+      if (c < cols) {
+        const float xh = (TR::to_f32(xr[c]) - mean) * rstd;
+        float gy = TR::to_f32(gr[c]);
+        dg[k] += gy * xh;
+        db[k] += gy;
+        gy *= TR::to_f32(gamma[c]);
+        s1 += gy;
+        s2 += gy * xh;
+      }
+    }
+    s1 = block_sum<kWaves>(s1, scratch) * inv_n;
+    s2 = block_sum<kWaves>(s2, scratch) * inv_n;
+#pragma unroll
+    for (int k = 0; k < kRowCols; ++k) {
+      const int c = threadIdx.x + k * kThreads;
+      if (c < cols) {
+        float o = rstd * (TR::to_f32(gr[c]) * TR::to_f32(gamma[c]) - s1 - (TR::to_f32(xr[c]) - mean) * rstd * s2);
+        if (dres) o += TR::to_f32(dres[row * cols + c]);
+        if (DSUM) ds[k] += o;
+        dx[row * cols + c] = TR::from_f32(o);
+      }
+    }
+  }
+  float* out = partial + static_cast<size_t>(blockIdx.x) * NACC * cols;
+#pragma unroll
+  for (int k = 0; k < kRowCols; ++k) {
+    const int c = threadIdx.x + k * kThreads;
+    if (c < cols) {
+      out[c] = dg[k];
+      out[cols + c] = db[k];
+      if (DSUM) out[2 * cols + c] = ds[k];
+    }
+  }
+}
+
 int pick_blocks(long long rows) {
   long long b = (rows + kWaves - 1) / kWaves;
   if (b > kMaxBlocks) b = kMaxBlocks;
@@ -359,6 +470,14 @@ bool dispatch_shape(long long cols, int limit16, F&& f) {
 
 }  // namespace
 
+// The wave-per-row backward kernel: rows of a whole number of 16-byte vectors, at most 4 per lane, and at most 1365
+// columns when the column sums of dx are wanted as well (its three accumulator rows live in LDS).
+bool layernorm_bwd_in_registers(long long cols, int dtype, bool want_dsum) {
+  const long long vec = dtype == kF32 ? 4 : 8;
+  return cols % vec == 0 && cols <= 64 * vec * 4 && (!want_dsum || cols <= 1365);
+}
+bool layernorm_supported(long long cols) { return cols >= 1 && cols <= kRowMaxCols; }
+
 void launch_layernorm_fwd(const void* x, const void* res, const void* res_bias, void* sum_out, const void* gamma, const void* beta, void* y,
                           float* mean, float* rstd, long long rows, long long cols, float eps, int dtype, hipStream_t stream) {
   if (rows <= 0) return;
@@ -367,13 +486,20 @@ void launch_layernorm_fwd(const void* x, const void* res, const void* res_bias, 
     using T = typename TR::T;
     long long blocks = (rows + kWaves - 1) / kWaves;
     if (blocks > 4096) blocks = 4096;
-    dispatch_shape<TR>(cols, 8, [&](auto vv, auto mv) {
+    const bool in_registers = cols % TR::kVec == 0 && dispatch_shape<TR>(cols, 8, [&](auto vv, auto mv) {
       constexpr int V = decltype(vv)::value, MAXV = decltype(mv)::value;
       hipLaunchKernelGGL((layernorm_fwd_kernel<TR, V, MAXV>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, stream,
                          static_cast<const T*>(x), static_cast<const T*>(res), static_cast<const T*>(res_bias), static_cast<T*>(sum_out),
                          static_cast<const T*>(gamma),
                          static_cast<const T*>(beta), static_cast<T*>(y), mean, rstd, rows, static_cast<int>(cols), eps);
     });
+    if (!in_registers) {
+      const long long row_blocks = rows < 8192 ? rows : 8192;
+      hipLaunchKernelGGL((layernorm_fwd_row_kernel<TR>), dim3(static_cast<unsigned>(row_blocks)), dim3(kThreads), 0, stream,
+                         static_cast<const T*>(x), static_cast<const T*>(res), static_cast<const T*>(res_bias), static_cast<T*>(sum_out),
+                         static_cast<const T*>(gamma), static_cast<const T*>(beta), static_cast<T*>(y), mean, rstd, rows, static_cast<int>(cols),
+                         eps);
+    }
   });
 }
 
@@ -389,7 +515,18 @@ void launch_layernorm_bwd(const void* dy, const void* x, const void* dres, const
     const int blocks = pick_blocks(rows);
     const int nacc = dsum ? 3 : 2;
     const size_t lds = static_cast<size_t>(nacc) * cols * sizeof(float);
-    dispatch_shape<TR>(cols, 4, [&](auto vv, auto mv) {
+    const bool in_registers = layernorm_bwd_in_registers(cols, dtype, dsum != nullptr);
+    if (!in_registers) {
+      if (dsum)
+        hipLaunchKernelGGL((layernorm_bwd_row_kernel<TR, true>), dim3(blocks), dim3(kThreads), 0, stream, static_cast<const T*>(dy),
+                           static_cast<const T*>(x), static_cast<const T*>(dres), static_cast<const T*>(gamma), mean, rstd, static_cast<T*>(dx),
+                           workspace, rows, static_cast<int>(cols));
+      else
+        hipLaunchKernelGGL((layernorm_bwd_row_kernel<TR, false>), dim3(blocks), dim3(kThreads), 0, stream, static_cast<const T*>(dy),
+                           static_cast<const T*>(x), static_cast<const T*>(dres), static_cast<const T*>(gamma), mean, rstd, static_cast<T*>(dx),
+                           workspace, rows, static_cast<int>(cols));
+    }
+    if (in_registers) dispatch_shape<TR>(cols, 4, [&](auto vv, auto mv) {
       constexpr int V = decltype(vv)::value;
       constexpr int MAXV = decltype(mv)::value > 5 ? 4 : decltype(mv)::value;
       auto go = [&](auto ds_tag) {

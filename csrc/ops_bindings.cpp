@@ -830,10 +830,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_forward(Tensor x, Tensor ga
   const int64_t rows = x.size(0), cols = x.size(1);
   TORCH_CHECK(gamma.numel() == cols && beta.numel() == cols, "layernorm_forward: affine parameters must be [cols]");
   TORCH_CHECK(gamma.scalar_type() == x.scalar_type() && beta.scalar_type() == x.scalar_type(), "layernorm_forward: dtype mismatch");
-  {
-    const int64_t vec = 16 / x.element_size();
-    TORCH_CHECK(cols % vec == 0 && cols <= 64 * vec * 8, "layernorm_forward: cols must be a multiple of ", vec, " and at most ", 64 * vec * 8);
-  }
+  TORCH_CHECK(kernels::layernorm_supported(cols), "layernorm_forward: at most 8192 columns");
   Tensor y = at::empty_like(x);
   Tensor sum = x;
   const void* res_ptr = nullptr;
@@ -872,10 +869,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor 
   const int64_t rows = x.size(0), cols = x.size(1);
   TORCH_CHECK(gamma.numel() == cols && mean.numel() == rows && rstd.numel() == rows, "layernorm_backward: size mismatch");
   TORCH_CHECK(mean.scalar_type() == at::kFloat && rstd.scalar_type() == at::kFloat, "layernorm_backward: statistics must be float32");
-  {
-    const int64_t vec = 16 / x.element_size();
-    TORCH_CHECK(cols % vec == 0 && cols <= 64 * vec * 4, "layernorm_backward: cols must be a multiple of ", vec, " and at most ", 64 * vec * 4);
-  }
+  TORCH_CHECK(kernels::layernorm_supported(cols), "layernorm_backward: at most 8192 columns");
   const void* dres_ptr = nullptr;
   if (dres.has_value()) {
     check_gpu(*dres, "dres");
@@ -883,7 +877,6 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> layernorm_backward(Tensor dy, Tensor 
                 "layernorm_backward: dres must match x");
     dres_ptr = dres->data_ptr();
   }
-  TORCH_CHECK(!want_dsum || cols <= 1365, "layernorm_backward: the fused column sum of dx supports at most 1365 columns");
   Tensor dx = at::empty_like(x), dgamma = at::empty_like(gamma), dbeta = at::empty_like(gamma);
   Tensor dsum = want_dsum ? at::empty_like(gamma) : Tensor();
   Tensor ws = at::empty({kernels::layernorm_bwd_workspace(rows, cols)}, x.options().dtype(at::kFloat));
@@ -1054,6 +1047,7 @@ void init_ops(py::module_& m) {
         py::arg("relu") = false);
   m.def("batchnorm_backward", &batchnorm_backward, py::arg("dy"), py::arg("x"), py::arg("y"), py::arg("scale_shift"), py::arg("weight"),
         py::arg("mean"), py::arg("rstd"), py::arg("relu") = false, py::arg("want_dres") = false);
+  m.def("layernorm_supported", &kernels::layernorm_supported, py::arg("cols"));
   m.def("layernorm_forward", &layernorm_forward, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("eps") = 1e-5,
         py::arg("res") = py::none(), py::arg("res_bias") = py::none());
   m.def("layernorm_backward", &layernorm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"), py::arg("rstd"),

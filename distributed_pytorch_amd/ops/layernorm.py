@@ -16,8 +16,7 @@ from .. import _ext
 def _supported(x: torch.Tensor, cols: int, need_grad: bool) -> bool:
     if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         return False
-    vec = 16 // x.element_size()
-    return cols % vec == 0 and cols <= 64 * vec * (4 if need_grad else 8)
+    return 1 <= cols <= 8192  # any width: register-resident rows where they fit, a workgroup per row otherwise
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -105,7 +104,7 @@ def add_layer_norm(x: torch.Tensor, r, weight: torch.Tensor, bias: torch.Tensor,
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         s, y = _KeepLayerNorm.apply(x2, weight.contiguous(), bias.contiguous(), eps)
         return s.reshape(x.shape), y.reshape(x.shape)
-    if r_bias is not None and (not x.is_cuda or cols > 1365 or r_bias.dtype != x.dtype):
+    if r_bias is not None and (not x.is_cuda or cols > 8192 or r_bias.dtype != x.dtype):
         r = r + r_bias
         r_bias = None
     need_grad = torch.is_grad_enabled() and (x.requires_grad or r.requires_grad or weight.requires_grad)

@@ -453,14 +453,16 @@ def test_gemm_large_random_f32_and_bf16():
 
 
 # ----------------------------------------------------------------------------- layer norm
-@pytest.mark.parametrize("rows,cols", [(1, 768), (5, 768), (4097, 768), (33, 64), (16, 1024), (7, 2048), (9, 1280), (12, 256), (6, 384), (10, 320)])
+@pytest.mark.parametrize("rows,cols", [(1, 768), (5, 768), (4097, 768), (33, 64), (16, 1024), (7, 2048), (9, 1280), (12, 256), (6, 384), (10, 320),
+                                       (300, 1600), (5, 4096), (3, 8192), (37, 1001), (600, 5), (2, 7777)])  # the last six: one workgroup per row
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm(rows, cols, dtype):
-    from distributed_pytorch_amd.ops.layernorm import layer_norm
+    """Widths that a wave keeps in registers, widths beyond that (fp32 backward > 1024 columns, anything > 2048 / 4096) and
+    widths that are not a multiple of the 16-byte vector all run on native kernels."""
+    from distributed_pytorch_amd.ops.layernorm import _supported, layer_norm
 
-    if dtype == torch.float32 and cols > 1024:
-        pytest.skip("fp32 backward keeps at most 1024 columns in registers")
     torch.manual_seed(rows + cols)
+    assert _supported(torch.empty(1, cols, device=DEV, dtype=dtype), cols, True) and C().layernorm_supported(cols)
     x = (torch.randn(rows, cols, device=DEV) * 2 + 0.5).to(dtype)
     g = torch.randn(cols, device=DEV).to(dtype)
     b = torch.randn(cols, device=DEV).to(dtype)
@@ -709,7 +711,8 @@ def test_gemm_bf16_split_k_exact_integers(a_k, b_k, M, N, K):
     assert torch.equal(out, again)  # deterministic reduction order
 
 
-@pytest.mark.parametrize("rows,cols,dtype", [(300, 768, torch.bfloat16), (64, 1024, torch.bfloat16), (33, 256, torch.float32)])
+@pytest.mark.parametrize("rows,cols,dtype", [(300, 768, torch.bfloat16), (64, 1024, torch.bfloat16), (33, 256, torch.float32),
+                                             (40, 1280, torch.float32), (21, 5120, torch.bfloat16), (9, 1003, torch.bfloat16)])  # the last three: one workgroup per row
 def test_add_layernorm_fused_matches_unfused(rows, cols, dtype):
     """s = x + r, y = LN(s) in one kernel; backward folds the gradient arriving at s into dx."""
     from distributed_pytorch_amd.ops.layernorm import add_layer_norm, layer_norm
@@ -815,13 +818,13 @@ def test_fused_loss_kernel_row_in_registers_and_fallbacks(ld, nc, dtype):
     assert torch.count_nonzero(work[:, nc:]) == 0 and torch.count_nonzero(work[5]) == 0
 
 
-def test_add_layernorm_with_branch_bias_and_its_gradient():
+@pytest.mark.parametrize("rows,cols", [(700, 768), (130, 1600), (64, 2500)])  # wave per row; workgroup per row (> 1365 columns with the column sum)
+def test_add_layernorm_with_branch_bias_and_its_gradient(rows, cols):
     """s = x + r + r_bias in the forward kernel; the backward kernel also returns colsum(ds), the
     gradient of r_bias, next to dgamma / dbeta."""
     from distributed_pytorch_amd.ops.layernorm import add_layer_norm
 
     torch.manual_seed(5)
-    rows, cols = 700, 768
     x = torch.randn(rows, cols, device=DEV).bfloat16()
     r = torch.randn(rows, cols, device=DEV).bfloat16()
     rb = torch.randn(cols, device=DEV).bfloat16()

@@ -36,6 +36,10 @@ namespace kernels {
 
 namespace {
 
+#ifndef FWD32_WAVES_PER_SIMD
+#define FWD32_WAVES_PER_SIMD 2
+#endif
+
 constexpr int HD = 64;        // head dimension
 constexpr int BQ = 128;       // queries per workgroup
 constexpr int BKV = 64;       // keys per tile
@@ -1669,6 +1673,173 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv32_kernel(AttnBwdPar
   }
 }
 
+// =====================================================================================
+// Forward on v_mfma_f32_32x32x16_bf16 with the FIRST kernel's structure (32 queries per wave, 64-key tiles through the
+// same three-stage LDS-DMA ring, one barrier per tile, all overlap left to the waves that share a SIMD): 16 matrix
+// instructions per 32 x 64 tile instead of 36.  A matrix instruction holds the issue port it shares with the vector ALU
+// for ~20 cycles whatever its shape, and the first kernel's tile loop runs within 10 % of what that port allows (36 x 20
+// + ~640 cycles of vector work per wave and tile against 1465 measured), so this is the direct remedy; the wave also
+// needs fewer registers; a third workgroup per CU (168 registers, a few spills) measured the same as two.
+// Measured: 210-216 us at B64 x H12 x T1024 against 213-220 us for the first kernel and 207-210 us for the 64-query one;
+// 30.3 vs 31.9 us at B8; 91-94 vs 95 us at B96 x T512 -- a few per cent, not the 29 % the port arithmetic promised:
+// with matrix, vector and transcendental instructions sharing a SIMD's issue, all three forward kernels end up within
+// 3 % of each other.
+// K tile in the k_off image (row-wise reads), V tile in the v2_off image (transposing reads), as in the 64-query kernel.
+// =====================================================================================
+__device__ __forceinline__ const u16* dma_src_v2(const u16* base, long long row_stride, int piece, int lane) {
+  const int r = piece * 8 + (lane >> 3), pc = lane & 7;
+  return base + static_cast<long long>(r) * row_stride + (pc ^ (((r >> 1) & 1) << 2)) * 8;
+}
+
+template <bool MASK>
+__device__ __forceinline__ void fwd32_tile(const char* ks, const char* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], float& m, float& l,
+                                           int key0, int q0, int lane, float c, int koff, int voff) {
+  const int hi = lane >> 5, lq = lane & 31;
+  bf16x2 ones;
+  ones[0] = static_cast<__bf16>(1.f);
+  ones[1] = static_cast<__bf16>(1.f);
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    if (MASK && key0 + 32 * kb > q0 + 31) break;  // every key of the block is in the future of every query of the wave
+    bf16x8 kf[4];
+    wide_load_k(ks, kb * kBlkBytes + koff, kf);
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ds], qf[ds], s, 0, 0, 0);
+    bf16x8 vf[2][2];
+    wide_load_v(vs, kb * kBlkBytes + voff, vf);
+    if (MASK) {
+      const int rel = q0 + lq - key0 - 32 * kb - 4 * hi;  // register i holds key (i & 3) + 8 * (i >> 2) of the lane half
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if ((i & 3) + 8 * (i >> 2) > rel) s[i] = -__builtin_huge_valf();
+    }
+    float t = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, s[i]), s[i + 1]);
+    const float mx = fmaxf(t, s[15]) * c;
+    if (__any(mx > m + kDeferLog2)) {  // rare after the first tile: some query's maximum moved a lot
+      const float mg = half_swap_max(mx);
+      const float m_new = mg > m + kDeferLog2 ? mg : m;
+      const float alpha = m_new == m ? 1.f : fast_exp2(m - m_new);
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+    }
+    const float nm = -m;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      unsigned w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x2 v;
+        v[0] = static_cast<__bf16>(fast_exp2(fmaf(s[8 * s2 + 2 * j], c, nm)));
+        v[1] = static_cast<__bf16>(fast_exp2(fmaf(s[8 * s2 + 2 * j + 1], c, nm)));
+        l = __builtin_amdgcn_fdot2_f32_bf16(v, ones, l, false);
+        w[j] = __builtin_bit_cast(unsigned, v);
+      }
+      const u32x4 packed = {w[0], w[1], w[2], w[3]};
+      pf[s2] = __builtin_bit_cast(bf16x8, packed);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][s2], pf[s2], o[db], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void attn_fwd32_block(const AttnParams& p, char* smem, int bh, int qb, int round) {
+  const int b = bh / p.H, h = bh % p.H;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int q0 = qb * BQ + wid * 32;
+
+  const long long head_off = static_cast<long long>(b) * p.T * p.row_stride + static_cast<long long>(h) * HD;
+  const u16* Q = p.q + head_off;
+  const u16* K = p.k + head_off;
+  const u16* V = p.v + head_off;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+  float m = -__builtin_huge_valf(), l = 0.f;
+
+  const int koff = k_off(lq, hi);
+  int voff;
+  {
+    const int i = lane & 15, g1 = (lane >> 4) & 1, pp = i & 3, row = 4 * hi + (i >> 2);
+    voff = v2_off(row, 2 * g1 + (pp >> 1)) + ((pp & 1) << 3);
+  }
+  // the first kernel's ring: waves 0-1 move K pieces, waves 2-3 V pieces, four 1-KiB pieces per wave and tile
+  const int n_tiles = (qb * BQ + BQ) / BKV;
+  const bool moves_v = wid >= 2;
+  const int piece0 = (wid & 1) * 4;
+  const u16* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    src[i] = moves_v ? dma_src_v2(V, p.row_stride, piece0 + i, lane) : dma_src<false>(K, p.row_stride, piece0 + i, lane);
+  const long long tile_step = static_cast<long long>(BKV) * p.row_stride;
+  const int dst0 = (moves_v ? kTileBytes : 0) + piece0 * 1024;
+  const unsigned smem_addr = lds_address(smem);
+  auto request = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma_16B(src[i], smem_addr + stage * 2 * kTileBytes + dst0 + i * 1024);
+      src[i] += tile_step;
+    }
+  };
+  __syncthreads();  // the previous block's output strips (same memory) have been read back by every wave
+  request(0);
+  if (n_tiles > 1) request(1);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(Q + static_cast<long long>(q0 + lq) * p.row_stride + 16 * ds + 8 * hi);
+  wait_all_vmem();
+
+  int stage = 0;
+  for (int jt = 0; jt < n_tiles; ++jt) {
+    take_turns(jt + round);
+    if (jt + 1 < n_tiles) wait_vmem_at_most<4>();
+    else wait_vmem_at_most<0>();
+    __syncthreads();
+    if (jt + 2 < n_tiles) request(stage == 0 ? 2 : stage - 1);
+    const char* ks = smem + stage * 2 * kTileBytes;
+    const char* vs = ks + kTileBytes;
+    const int key0 = jt * BKV;
+    if (key0 <= q0 + 31) {
+      if (key0 + BKV - 1 > q0) fwd32_tile<true>(ks, vs, qf, o, m, l, key0, q0, lane, p.scale_log2, koff, voff);
+      else fwd32_tile<false>(ks, vs, qf, o, m, l, key0, q0, lane, p.scale_log2, koff, voff);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  const float lt = half_swap_sum(l);
+  if (hi == 0) p.lse[(static_cast<long long>(b) * p.H + h) * p.T + q0 + lq] = (m + log2f(lt)) * 0.6931471805599453f;
+  __syncthreads();  // all waves are done with the tile stages: their memory becomes the output strips
+  const long long o_stride = static_cast<long long>(p.H) * HD;
+  store_rows32_staged<true>(smem + wid * kOutStripBytes, o, 1.f / lt, p.o + (static_cast<long long>(b) * p.T + q0) * o_stride + static_cast<long long>(h) * HD,
+                            o_stride, lane);
+}
+
+__global__ __launch_bounds__(kThreads, FWD32_WAVES_PER_SIMD) void attn_fwd32_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(1024))) char smem[6 * kTileBytes];  // [3 stages][K | V]
+  const int round = dispatch_round(p.per_cu);
+  const int nqb = p.T / BQ, per_head = (nqb + 1) >> 1, n_items = per_head * p.B * p.H;
+  for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
+    int pair, bh;
+    item_of_index(idx, n_items, per_head, pair, bh);
+    const int hi = nqb - 1 - pair;
+    for (int half = 0; half < (pair != hi ? 2 : 1); ++half) attn_fwd32_block(p, smem, bh, half == 0 ? hi : pair, round);
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -1682,12 +1853,13 @@ int resident_per_cu(Kernel kernel, int threads = kThreads) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
   return per_cu;
 }
-// DPA_ATTN_FWD=classic|wide forces one forward kernel (default: the wide one where it pays, see launch_attention_fwd);
+// DPA_ATTN_FWD=classic|wide|tile32 forces one forward kernel (default: wide where it pays, else classic -- see launch_attention_fwd);
 // DPA_ATTN_WIDE_PER_CU caps the wide kernel's workgroups per CU.
 int wide_forward_mode() {
   const char* e = getenv("DPA_ATTN_FWD");
   if (e && e[0] == 'c') return 0;
   if (e && e[0] == 'w') return 2;
+  if (e && e[0] == 't') return 3;  // "tile32"
   return 1;
 }
 // DPA_ATTN_BWD=classic|wide forces the backward kernels on 16x16x32 / 32x32x16 matrix instructions.  Default: the former --
@@ -1741,7 +1913,13 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
   // B32-64 x H12 x T1024, B16 x H16 x T2048, B4 x H16 x T4096) once those fill its grid and the rows are long, ties
   // around that point (B22-24 x H12 x T1024, B96 x H12 x T512) and loses below (B8 x H12 x T1024: 39 vs 32 us,
   // B2 x H16 x T4096: 129 vs 107 us, B48 x H12 x T512: 55 vs 52 us).
-  static const int env_mode = wide_forward_mode();  // 0 never, 1 when it pays, 2 whenever possible
+  static const int env_mode = wide_forward_mode();  // 0 never, 1 when it pays, 2 whenever possible, 3: the 32-query 32x32x16 kernel
+  auto launch_tile32 = [&]() {
+    static const int per_cu32 = resident_per_cu(attn_fwd32_kernel);
+    p.per_cu = per_cu32;
+    hipLaunchKernelGGL(attn_fwd32_kernel, dim3(persistent_grid(per_cu32, T, B, H)), dim3(kThreads), 0, stream, p);
+  };
+  if (kernel == 2 || (kernel < 0 && env_mode == 3)) return launch_tile32();
   const int wide_mode = kernel == 0 ? 0 : kernel == 1 ? 2 : env_mode;
   if (wide_mode > 0 && (static_cast<long long>(B) * H) % 2 == 0) {
     static const int per_cu = wide_per_cu();
@@ -1753,6 +1931,8 @@ void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, 
       return;
     }
   }
+  // (The 32-query kernel on 32x32x16 instructions measured 0-5 % ahead of the first kernel alone on every shape tried
+  // and 0.7 % behind it inside a batch-16 GPT-2 step: selectable, not the default.)
   static const int fwd_per_cu = resident_per_cu(attn_fwd_kernel);
   p.per_cu = fwd_per_cu;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(persistent_grid(fwd_per_cu, T, B, H)), dim3(kThreads), 0, stream, p);

@@ -253,8 +253,9 @@ void launch_batchnorm_bwd(const void* dy, const void* x, const void* y, const fl
 // [B, T, 3, H, 64] projection has row_stride = 3*H*64 and k = q + H*64, v = q + 2*H*64).
 // o / do are [B, T, H, 64] contiguous; lse is [B, H, T] fp32; delta is a workspace of 2*B*H*T floats.
 bool attention_supported(long long T, long long head_dim, long long row_stride);
-// `kernel`: -1 = choose (environment DPA_ATTN_FWD=classic|wide overrides), 0 = the two-waves-per-SIMD kernel, 1 = the
-// one with 64 queries per wave (needs B*H even; falls back to 0 otherwise).
+// `kernel`: -1 = choose by shape (environment DPA_ATTN_FWD=classic|wide|tile32 overrides), 0 = the first kernel (32 queries
+// per wave, 16x16x32 matrix instructions), 1 = 64 queries per wave on 32x32x16 (needs B*H even; falls back otherwise),
+// 2 = 32 queries per wave on 32x32x16.
 void launch_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                           long long row_stride, int B, int H, int T, float softmax_scale,
                           hipStream_t stream, int kernel = -1);

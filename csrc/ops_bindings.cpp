@@ -901,11 +901,11 @@ std::tuple<Tensor, Tensor> attention_forward(Tensor qkv, int64_t n_head, double 
   Tensor lse = at::empty({B, n_head, T}, qkv.options().dtype(at::kFloat));
   DevGuard guard(qkv);
   const char* base = static_cast<const char*>(qkv.data_ptr());
-  TORCH_CHECK(kernel == "auto" || kernel == "classic" || kernel == "wide", "attention_forward: kernel must be auto, classic or wide");
+  TORCH_CHECK(kernel == "auto" || kernel == "classic" || kernel == "wide" || kernel == "tile32", "attention_forward: kernel must be auto, classic, wide or tile32");
   TORCH_CHECK(kernel != "wide" || (B * n_head) % 2 == 0, "attention_forward: the wide kernel takes heads two at a time, B * n_head must be even");
   kernels::launch_attention_fwd(base, base + Cd * 2, base + 2 * Cd * 2, o.data_ptr(), lse.data_ptr<float>(), C3, static_cast<int>(B),
                                 static_cast<int>(n_head), static_cast<int>(T), static_cast<float>(softmax_scale), stream_of(qkv),
-                                kernel == "auto" ? -1 : kernel == "wide" ? 1 : 0);
+                                kernel == "auto" ? -1 : kernel == "wide" ? 1 : kernel == "tile32" ? 2 : 0);
   return {o, lse};
 }
 

@@ -529,7 +529,7 @@ def _attention_reference(qkv, H, scale):
     return (q, k, v), o, lse
 
 
-@pytest.mark.parametrize("kernel", ["classic", "wide"])
+@pytest.mark.parametrize("kernel", ["classic", "wide", "tile32"])
 @pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 256, 3), (1, 640, 2), (2, 1024, 12), (1, 128, 2), (2, 384, 5)])
 def test_flash_attention_forward_backward(B, T, H, kernel):
     if kernel == "wide" and (B * H) % 2:
@@ -555,7 +555,7 @@ def test_flash_attention_forward_backward(B, T, H, kernel):
         assert err <= 1e-2 * ref_g.abs().max().item() + 1e-2, (bwd_kernel, err)
 
 
-@pytest.mark.parametrize("kernel", ["classic", "wide"])
+@pytest.mark.parametrize("kernel", ["classic", "wide", "tile32"])
 def test_flash_attention_large_logits_and_causality(kernel):
     """Scores of magnitude ~60 (softmax saturates) stay finite, and outputs at position t do not
     depend on inputs after t."""
@@ -580,7 +580,7 @@ def test_flash_attention_large_logits_and_causality(kernel):
         assert torch.count_nonzero(d[:, 130:].float()) == 0  # no gradient flows to later positions
 
 
-@pytest.mark.parametrize("kernel", ["classic", "wide"])
+@pytest.mark.parametrize("kernel", ["classic", "wide", "tile32"])
 def test_flash_attention_growing_maximum(kernel):
     """Scores that keep growing along the keys (every block raises the running maximum by far more than the deferral
     threshold) exercise the rescale of the partial output and row sum in every step."""

@@ -24,7 +24,7 @@ print(f"{t*1e3:.1f} us {fl/t/1e9:.0f} TF")
 '''
 for B, T, H in shapes:
     row = []
-    for kind in ("classic", "wide", "classic", "wide"):
+    for kind in ("classic", "wide", "tile32", "classic", "wide", "tile32"):
         env = dict(os.environ, DPA_ATTN_FWD=kind)
         out = subprocess.run([sys.executable, "-c", code, str(B), str(T), str(H)], env=env, capture_output=True, text=True, timeout=120)
         row.append(f"{kind}: {out.stdout.strip() or out.stderr.strip()[-200:]}")

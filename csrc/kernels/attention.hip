@@ -236,6 +236,21 @@ __device__ __forceinline__ void store_rows_staged(char* strip, const f32x4 (&acc
   }
 }
 
+// Column sums of a workgroup's 128 output rows (bias gradient pieces): every wave has left the sums of its 32 rows in
+// `red[wid][64]` (LDS, through the `colsum` argument of the row stores); after a barrier the first wave adds the four
+// and writes one row of the partial-sum tensor -- a quarter of the rows (and of the traffic of the reduction that
+// follows) that one row per wave would need.  `n_sets`: how many [4][64] sets were filled (dK and dV share a barrier).
+constexpr int kColsumSetFloats = 4 * 64;
+__device__ __forceinline__ void emit_block_colsums(const float* red, int n_sets, float* const (&dst)[2], int lane, int wid) {
+  __syncthreads();
+  if (wid == 0) {
+    for (int s = 0; s < n_sets; ++s) {
+      const float* r = red + s * kColsumSetFloats;
+      dst[s][lane] = (r[lane] + r[64 + lane]) + (r[128 + lane] + r[192 + lane]);
+    }
+  }
+}
+
 // Online-softmax update of one 16-query strip: scores s (S^T accumulators of the strip's four
 // 16-key tiles) -> bf16 probabilities packed as the two B operands of the P.V product.  The loop is
 // bound by vector issue slots, not by the matrix pipe, so the work per score is one v_fma_f32 and one
@@ -962,7 +977,7 @@ struct AttnBwdParams {
   const float* lse;   // [B, H, T]
   float* delta;       // [B, H, T]: sum_d dO*O, written by the dQ kernel and read by the dK/dV kernel
   float* lse2;        // [B, H, T]: lse * log2(e), likewise
-  float* bias_partial;  // nullptr, or [B*T/32][3*H*64]: column sums of dq | dk | dv per block of 32 positions
+  float* bias_partial;  // nullptr, or [B*T/128][3*H*64]: column sums of dq | dk | dv per block of 128 positions
   u16* dq;            // gradient tensors use grad_row_stride between consecutive t
   u16* dk;
   u16* dv;
@@ -1113,9 +1128,14 @@ __device__ __forceinline__ void attn_bwd_dq_block(const AttnBwdParams& p, char* 
   __syncthreads();  // tile stages -> output strips
   const float by_scale[2] = {p.scale, p.scale};
   const long long C3 = 3LL * p.H * HD;
-  float* bq = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + q0) >> 5) * C3 + static_cast<long long>(h) * HD : nullptr;
+  float* red = reinterpret_cast<float*>(smem + 4 * kOutStripBytes);  // behind the four strips
   store_rows_staged<true>(smem + wid * kOutStripBytes, dq, by_scale,
-                    p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD, p.grad_row_stride, lane, bq);
+                    p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD, p.grad_row_stride, lane,
+                    p.bias_partial ? red + wid * 64 : nullptr);
+  if (p.bias_partial) {
+    float* const dst[2] = {p.bias_partial + ((static_cast<long long>(b) * p.T + qb * BQ) >> 7) * C3 + static_cast<long long>(h) * HD, nullptr};
+    emit_block_colsums(red, 1, dst, lane, wid);
+  }
 }
 
 __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
@@ -1301,11 +1321,17 @@ __device__ __forceinline__ void attn_bwd_dkdv_block(const AttnBwdParams& p, char
   const float one[2] = {1.f, 1.f};
   const long long out_off = (static_cast<long long>(b) * p.T + k0w) * p.grad_row_stride + static_cast<long long>(h) * HD;
   const long long C3 = 3LL * p.H * HD;
-  float* bk = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + k0w) >> 5) * C3 + (p.H + h) * static_cast<long long>(HD) : nullptr;
-  float* bvp = bk ? bk + static_cast<long long>(p.H) * HD : nullptr;
+  float* red = reinterpret_cast<float*>(smem + 4 * kOutStripBytes);  // behind the four strips: one set for dK, one for dV
   const float by_scale[2] = {p.scale, p.scale};
-  store_rows_staged<true>(smem + wid * kOutStripBytes, dk, by_scale, p.dk + out_off, p.grad_row_stride, lane, bk);
-  store_rows_staged<true>(smem + wid * kOutStripBytes, dv, one, p.dv + out_off, p.grad_row_stride, lane, bvp);
+  store_rows_staged<true>(smem + wid * kOutStripBytes, dk, by_scale, p.dk + out_off, p.grad_row_stride, lane,
+                          p.bias_partial ? red + wid * 64 : nullptr);
+  store_rows_staged<true>(smem + wid * kOutStripBytes, dv, one, p.dv + out_off, p.grad_row_stride, lane,
+                          p.bias_partial ? red + kColsumSetFloats + wid * 64 : nullptr);
+  if (p.bias_partial) {
+    float* bk = p.bias_partial + ((static_cast<long long>(b) * p.T + jb * BQ) >> 7) * C3 + (p.H + h) * static_cast<long long>(HD);
+    float* const dst[2] = {bk, bk + static_cast<long long>(p.H) * HD};
+    emit_block_colsums(red, 2, dst, lane, wid);
+  }
 }
 
 __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv_kernel(AttnBwdParams p) {
@@ -1504,10 +1530,14 @@ __device__ __forceinline__ void attn_bwd_dq32_block(const AttnBwdParams& p, char
   }
   __syncthreads();  // tile stages -> output strips
   const long long C3 = 3LL * p.H * HD;
-  float* bq = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + q0) >> 5) * C3 + static_cast<long long>(h) * HD : nullptr;
+  float* red = reinterpret_cast<float*>(smem + 4 * kOutStripBytes);
   store_rows32_staged<true>(smem + wid * kOutStripBytes, dq, p.scale,
                             p.dq + (static_cast<long long>(b) * p.T + q0) * p.grad_row_stride + static_cast<long long>(h) * HD,
-                            p.grad_row_stride, lane, bq);
+                            p.grad_row_stride, lane, p.bias_partial ? red + wid * 64 : nullptr);
+  if (p.bias_partial) {
+    float* const dst[2] = {p.bias_partial + ((static_cast<long long>(b) * p.T + qb * BQ) >> 7) * C3 + static_cast<long long>(h) * HD, nullptr};
+    emit_block_colsums(red, 1, dst, lane, wid);
+  }
 }
 
 __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dq32_kernel(AttnBwdParams p) {
@@ -1655,10 +1685,16 @@ __device__ __forceinline__ void attn_bwd_dkdv32_block(const AttnBwdParams& p, ch
   __syncthreads();  // tile stages -> output strips
   const long long out_off = (static_cast<long long>(b) * p.T + k0w) * p.grad_row_stride + static_cast<long long>(h) * HD;
   const long long C3 = 3LL * p.H * HD;
-  float* bk = p.bias_partial ? p.bias_partial + ((static_cast<long long>(b) * p.T + k0w) >> 5) * C3 + (p.H + h) * static_cast<long long>(HD) : nullptr;
-  float* bvp = bk ? bk + static_cast<long long>(p.H) * HD : nullptr;
-  store_rows32_staged<true>(smem + wid * kOutStripBytes, dk, p.scale, p.dk + out_off, p.grad_row_stride, lane, bk);
-  store_rows32_staged<true>(smem + wid * kOutStripBytes, dv, 1.f, p.dv + out_off, p.grad_row_stride, lane, bvp);
+  float* red = reinterpret_cast<float*>(smem + 4 * kOutStripBytes);
+  store_rows32_staged<true>(smem + wid * kOutStripBytes, dk, p.scale, p.dk + out_off, p.grad_row_stride, lane,
+                            p.bias_partial ? red + wid * 64 : nullptr);
+  store_rows32_staged<true>(smem + wid * kOutStripBytes, dv, 1.f, p.dv + out_off, p.grad_row_stride, lane,
+                            p.bias_partial ? red + kColsumSetFloats + wid * 64 : nullptr);
+  if (p.bias_partial) {
+    float* bk = p.bias_partial + ((static_cast<long long>(b) * p.T + jb * BQ) >> 7) * C3 + (p.H + h) * static_cast<long long>(HD);
+    float* const dst[2] = {bk, bk + static_cast<long long>(p.H) * HD};
+    emit_block_colsums(red, 2, dst, lane, wid);
+  }
 }
 
 __global__ __launch_bounds__(kThreads, 2) void attn_bwd_dkdv32_kernel(AttnBwdParams p) {

@@ -264,8 +264,8 @@ void launch_attention_bwd(const void* q, const void* k, const void* v, const voi
                           long long row_stride, long long grad_row_stride, int B, int H, int T,
                           float softmax_scale, float* bias_partial, hipStream_t stream, int kernel = -1);
 // kernel: -1 = choose (environment DPA_ATTN_BWD=classic|wide overrides), 0 = 16x16x32 matrix instructions, 1 = 32x32x16.
-// bias_partial: nullptr, or [B*T/32][3*H*64] fp32 receiving the column sums of dq | dk | dv per block
-// of 32 positions (summed over the first index they give the bias gradient of the q|k|v projection).
+// bias_partial: nullptr, or [B*T/128][3*H*64] fp32 receiving the column sums of dq | dk | dv per block
+// of 128 positions (summed over the first index they give the bias gradient of the q|k|v projection).
 
 }  // namespace kernels
 }  // namespace dpa

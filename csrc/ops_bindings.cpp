@@ -930,7 +930,7 @@ std::tuple<Tensor, Tensor> attention_backward(Tensor d_o, Tensor qkv, Tensor o, 
   Tensor delta = at::empty({2, B, n_head, T}, lse.options());  // delta | lse*log2(e), filled by the dQ kernel
   Tensor partial, dbias;
   if (want_bias_grad) {
-    partial = at::empty({B * T / 32, C3}, lse.options());
+    partial = at::empty({B * T / 128, C3}, lse.options());
     dbias = at::empty({C3}, qkv.options());
   }
   DevGuard guard(qkv);
@@ -941,7 +941,7 @@ std::tuple<Tensor, Tensor> attention_backward(Tensor d_o, Tensor qkv, Tensor o, 
                                 gbase, gbase + Cd * 2, gbase + 2 * Cd * 2, C3, C3, static_cast<int>(B), static_cast<int>(n_head),
                                 static_cast<int>(T), static_cast<float>(softmax_scale), want_bias_grad ? partial.data_ptr<float>() : nullptr, s,
                                 kernel == "auto" ? -1 : kernel == "wide" ? 1 : 0);
-  if (want_bias_grad) kernels::launch_reduce_partials(partial.data_ptr<float>(), dbias.data_ptr(), C3, static_cast<int>(B * T / 32), kernels::kBF16, s);
+  if (want_bias_grad) kernels::launch_reduce_partials(partial.data_ptr<float>(), dbias.data_ptr(), C3, static_cast<int>(B * T / 128), kernels::kBF16, s);
   return {dqkv, dbias};
 }
 

@@ -288,6 +288,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
 #define DPA_STAMP(i)
 #define DPA_STAMP_REAL(i)
 #endif
+// -DGEMM_TILE_TIMES (tools/kernel_harness/gemm_bench.hip): wave 0 records the 100 MHz clock at the start (slot 0) and
+// behind the last store (slot 1) of each of its first 128 tiles into p.colsum_partial.
+#ifdef GEMM_TILE_TIMES
+#define DPA_TILE_TIME(slot)                                                                                          \
+  do {                                                                                                               \
+    unsigned long long t_;                                                                                           \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                 \
+    if (threadIdx.x == 0 && tile_no < 128)                                                                           \
+      reinterpret_cast<unsigned long long*>(p.colsum_partial)[(blockIdx.x * 128 + tile_no) * 2 + (slot)] = t_;       \
+  } while (0)
+#else
+#define DPA_TILE_TIME(slot)
+#endif
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int kThreads2 = 512;
@@ -482,6 +495,15 @@ constexpr int kBiasOff = kCtrlOff + 64;                     // the next tile's 2
 constexpr int kLdsBytes2 = kBiasOff + 512;                  // 163,392 of the CU's 163,840 bytes
 constexpr int kNoTile = 0x7fffffff;
 using lds_u32_ptr = volatile __attribute__((address_space(3))) unsigned*;
+// The lane index, recomputed (two instructions) where the per-tile code needs it.  Kept in a register from the top of
+// the kernel it does not survive the tile loop's register pressure: it is spilled, and a reload from scratch memory
+// is an ordinary memory operation -- the compiler waits for it with vmcnt(0), which also waits for every LDS-DMA
+// request and output store in flight (found twice per tile, in the cursor move and in front of the bias request).
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 constexpr int kStreamingMaxKSteps = 64;  // beyond K = 4096 a tile is long enough to hide its own start
 
 // SPLIT: the grid is (tiles, ranges); every workgroup multiplies one contraction range of `k_iters` steps of one
@@ -569,16 +591,32 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   const char *r_aptr = nullptr, *r_bptr = nullptr;
   unsigned r_dst = lds_base + wid * 2048;  // this wave's first piece of half-tile 0 in the buffer being filled
   bool r_valid = true;
-  int cur = first_id;                                                       // tile being multiplied
-  int nxt = dynamic ? static_cast<int>(blockIdx.x + gridDim.x) : kNoTile;   // tile after it
+  // Dynamic walk: the id list is cut into eight contiguous segments, one per XCD (workgroup b runs on XCD b % 8).
+  // The W = gridDim.x / 8 workgroups of an XCD take local indices j and W + j of their segment, then indices drawn
+  // from the segment's own counter: at any time they multiply ~32 consecutive ids -- an 8 x 4 block of tiles, 12
+  // operand panels per k-step through that XCD's L2.  (One counter for the whole chip scatters every such block
+  // over all eight L2s: each then sees ~33 panels per k-step and misses 40 % of its requests.)  A workgroup whose
+  // segment is used up moves on to the next XCD's, so the kernel stays balanced when some CUs are held elsewhere.
+  const int seg_w = static_cast<int>(gridDim.x >> 3);
+  int seg = static_cast<int>(blockIdx.x & 7), seg_hops = 0, seg_start = 0, seg_len = 0;
+  auto seg_range = [&](int x) __attribute__((always_inline)) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    seg_start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    seg_len = q + (x < r ? 1 : 0);
+  };
+  if (dynamic) {
+    seg_range(seg);
+    first_id = seg_start + static_cast<int>(blockIdx.x >> 3);  // the launcher keeps 2 W <= seg_len
+  }
+  int cur = first_id;                                                                              // tile being multiplied
+  int nxt = dynamic ? seg_start + seg_w + static_cast<int>(blockIdx.x >> 3) : kNoTile;             // tile after it
   // per-lane source offsets of the cursor's tile (recomputed after every epilogue rather than kept across it)
   auto set_offsets = [&](int id) __attribute__((always_inline)) {
     long long rm0, rn0;
     tile_origin(id, rm0, rn0);
     // an opaque copy of the lane index: the compiler would otherwise hoist the lane-only parts of all eight
     // offsets to the top of the kernel and keep (spill) them across everything
-    int l = lane;
-    asm volatile("" : "+v"(l));
+    const int l = fresh_lane();
     if constexpr (CONV == 1) dma_offsets_conv_a(p, rm0, wid, l, off_a);
     else dma_offsets<A_KMAJOR, 64>(p.lda, rm0, p.M, wid, l, off_a);
     if constexpr (CONV == 2) dma_offsets_conv_b(p, rn0, wid, l, off_b);
@@ -679,9 +717,10 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   // dead.  LDS position (lane & 7) of row (lane >> 3) receives chunk (lane & 7) ^ (lane >> 3) of the row
   // (XOR on the source address), which spreads the accumulator-layout reads of the epilogue over the banks.
   const bool act_bwd = !SPLIT && p.aux_mode != kActNone;
-  const unsigned aux_off = static_cast<unsigned>(((lane >> 3) * p.ldc + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
   long long m0, n0;  // origin of the tile being multiplied
   auto aux_request = [&](int half, int buf) __attribute__((always_inline)) {
+    const int al = fresh_lane();
+    const unsigned aux_off = static_cast<unsigned>(((al >> 3) * p.ldc + (((al & 7) ^ (al >> 3)) << 3)) * 2);
     const char* src = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.aux) + (m0 + wm + 64 * half) * p.ldc + n0 + wn));
     const unsigned dst0 = lds_base + buf * 2 * kTileBytes2 + wid * 8192;
 #pragma unroll
@@ -701,7 +740,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   auto bias_request = [&](long long bn0) __attribute__((always_inline)) {
     if (wid != 0) return;
     const char* base = uniform_ptr(reinterpret_cast<const char*>(static_cast<const u16*>(p.bias) + bn0));
-    const unsigned voff = static_cast<unsigned>(lane * 4);
+    const unsigned voff = static_cast<unsigned>(fresh_lane() * 4);
     const unsigned dst = lds_base + kBiasOff;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory");
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(base + 256), "s"(dst + 256) : "memory");
@@ -738,7 +777,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     __builtin_amdgcn_sched_barrier(0);
     if (PENULT && dynamic && threadIdx.x == 0) {
       const unsigned one = 1u, zero = 0u;
-      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zero), "v"(one), "s"(tile_counter) : "memory");
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zero), "v"(one), "s"(tile_counter + seg) : "memory");
     }
     if (LAST && !SPLIT && p.bias != nullptr && nxt < ntiles) {
       long long bm0, bn0;
@@ -811,8 +850,10 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   phase_barrier();
   DPA_STAMP(1);
 
+  [[maybe_unused]] int tile_no = 0;
   while (true) {
     DPA_STAMP(6);
+    DPA_TILE_TIME(0);
     tile_origin(cur, m0, n0);
     // Full interior tiles of a plain product leave through the LDS-staged epilogue below (with the bias
     // already in the accumulators); everything else through the element-wise one.
@@ -820,9 +861,10 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
                         ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_act)) & 15) == 0;
     if (staged && p.bias != nullptr) {
       using lds_u16x4_cptr = const __attribute__((address_space(3))) u16x4*;
+      const int bias_lane = fresh_lane();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const u16x4 raw = *(lds_u16x4_cptr)(lds_base + kBiasOff + (wn + 16 * j + 4 * (lane >> 4)) * 2);
+        const u16x4 raw = *(lds_u16x4_cptr)(lds_base + kBiasOff + (wn + 16 * j + 4 * (bias_lane >> 4)) * 2);
         f32x4 b;
 #pragma unroll
         for (int e = 0; e < 4; ++e) b[e] = BF16::to_f32(raw[e]);
@@ -889,7 +931,8 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       aux_request(1, last);
       u16* Cout = static_cast<u16*>(p.C);
       float csum = 0.f;  // lane c: column n0 + wn + c of this wave's 128 rows
-      const int r = lane & 15, g = lane >> 4;
+      const int el = fresh_lane();
+      const int r = el & 15, g = el >> 4;
       const bool gelu = p.aux_mode == kActGelu;
       auto process = [&](int half, char* img) __attribute__((always_inline)) {
 #pragma unroll
@@ -920,14 +963,14 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
         if (p.colsum_partial) {
 #pragma unroll 8
           for (int rr = 0; rr < 64; ++rr)
-            csum += BF16::to_f32(*reinterpret_cast<const u16*>(img + rr * 128 + (((lane >> 3) ^ (rr & 7)) << 4) + (lane & 7) * 2));
+            csum += BF16::to_f32(*reinterpret_cast<const u16*>(img + rr * 128 + (((el >> 3) ^ (rr & 7)) << 4) + (el & 7) * 2));
         }
       };
       auto store_rows = [&](int half, const char* img) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-          const int rl = 8 * it + (lane >> 3), ch = (lane & 7) ^ (lane >> 3);
-          const u32x4 v = *reinterpret_cast<const u32x4*>(img + rl * 128 + (lane & 7) * 16);
+          const int rl = 8 * it + (el >> 3), ch = (el & 7) ^ (el >> 3);
+          const u32x4 v = *reinterpret_cast<const u32x4*>(img + rl * 128 + (el & 7) * 16);
           __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(Cout + (m0 + wm + 64 * half + rl) * p.ldc + n0 + wn + ch * 8));
         }
       };
@@ -940,14 +983,13 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       store_rows(0, img0);
       process(1, img1);
       store_rows(1, img1);
-      if (p.colsum_partial) p.colsum_partial[(2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + lane] = csum;
+      if (p.colsum_partial) p.colsum_partial[(2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + el] = csum;
       return;
     }
     if (staged) {
       using lds_u16x4_ptr = __attribute__((address_space(3))) u16x4*;
       using lds_u32x4_ptr = const __attribute__((address_space(3))) u32x4*;
-      int l = lane;
-      asm volatile("" : "+v"(l));  // the epilogue's lane constants are derived here, not kept from the top of the kernel
+      const int l = fresh_lane();  // the epilogue's lane constants are derived here, not kept from the top of the kernel
       const int r = l & 15, g = l >> 4;
       const unsigned mine = lds_base + kStageOff + wid * 2048;
       // + ((chunk ^ (r & 7)) << 4) per column tile; rows 8 .. 15 swap the 8-byte halves of a chunk, so that the 16
@@ -994,6 +1036,10 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
         // kernel ends, while the operand panels ARE re-read from L2 by the neighbouring tiles -- written the
         // normal way the output evicts them (measured on 131072 x 2304 x 768: 1124 -> 1241 TFLOP/s, x 768 x 768:
         // 1043 -> 1177; no change at K = 3072 where a tile's stores are a small share of its traffic).
+#ifdef GEMM_KO_ALL_STORES  // knock-out (tools/kernel_harness): what do the output stores cost?
+        asm volatile("" :: "v"(v[0][0]), "v"(v[0][3]), "v"(v[1][0]), "v"(v[1][3]), "v"(out));
+        return;
+#endif
         __builtin_nontemporal_store(v[0], reinterpret_cast<u32x4*>(out + static_cast<long long>(16 * i) * p.ldc));
         __builtin_nontemporal_store(u32x4{v[1][2], v[1][3], v[1][0], v[1][1]},
                                     reinterpret_cast<u32x4*>(out + static_cast<long long>(16 * i + 8) * p.ldc));
@@ -1016,7 +1062,12 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
               else convert_write((q + 1) >> 1, plain);
               read_rows(v[(q + 1) & 1]);
             }
+#ifdef GEMM_KO_PRE_STORE  // knock-out (tools/kernel_harness): the pre-activation passes run, their stores do not
+            if (q & 1) store_rows(c_rows, q >> 1, v[q & 1]);
+            else asm volatile("" :: "v"(v[0][0]), "v"(v[0][1]));
+#else
             store_rows(q & 1 ? c_rows : p_rows, q >> 1, v[q & 1]);
+#endif
           }
         } else {
           convert_write(0, act_c);
@@ -1045,12 +1096,33 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     }
     DPA_STAMP(3);
     DPA_STAMP_REAL(5);
+    DPA_TILE_TIME(1);
+#ifdef GEMM_TILE_TIMES
+    ++tile_no;
+#endif
     if (!dynamic) return;
     // next tile: the id drawn while this one was multiplied becomes the one after it
     cur = nxt;
     if (cur >= ntiles) return;
-    const unsigned drawn = __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
-    nxt = static_cast<int>(2u * gridDim.x + drawn);
+    unsigned local = 2u * seg_w + __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
+    // Segment used up (a handful of times per workgroup, at the end of the kernel): draw from the next ones, waiting
+    // for each answer -- every wave takes this path together, the value it branches on being the workgroup's.
+    while (local >= static_cast<unsigned>(seg_len) && seg_hops < 7) {
+      ++seg_hops;
+      seg = (seg + 1) & 7;
+      seg_range(seg);
+      phase_barrier();  // every wave has read the control word
+      if (threadIdx.x == 0) {
+        const unsigned one = 1u, zero = 0u;
+        unsigned got;
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(zero), "v"(one), "s"(tile_counter + seg) : "memory");
+        *(lds_u32_ptr)(smem2 + kCtrlOff) = got;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      phase_barrier();
+      local = 2u * seg_w + __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
+    }
+    nxt = local < static_cast<unsigned>(seg_len) ? seg_start + static_cast<int>(local) : kNoTile;
     set_offsets(cur);  // the cursor is inside this tile
   }
 }
@@ -1142,7 +1214,7 @@ bool gemm_bf16_supported(const GemmArgs& a) {
 
 // Tile counters of the streaming (several tiles per workgroup) launches: a small ring of 16-byte slots
 // in the code object's own memory, one per launch in flight, zeroed on the launch's stream.
-__device__ unsigned g_tile_counters[256 * 4];
+__device__ unsigned g_tile_counters[256 * 8];  // one set of eight (a counter per XCD segment) per launch in flight
 
 struct StreamingSetup {
   unsigned* counters = nullptr;
@@ -1200,9 +1272,12 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
     unsigned grid_x = static_cast<unsigned>(tiles);
     if (use_streaming(a, tiles, split)) {
       StreamingSetup& s = streaming_setup();
-      counter = s.counters + 4 * (s.next_slot++ & 255u);
-      (void)hipMemsetAsync(counter, 0, 16, stream);
-      grid_x = static_cast<unsigned>(s.cus);
+      counter = s.counters + 8 * (s.next_slot++ & 255u);
+      (void)hipMemsetAsync(counter, 0, 32, stream);
+      grid_x = static_cast<unsigned>(s.cus) & ~7u;  // the same number of workgroups on every XCD
+#ifdef GEMM_GRID_OVERRIDE  // experiment (tools/kernel_harness): fewer workgroups than CUs
+      grid_x = GEMM_GRID_OVERRIDE;
+#endif
     }
     const dim3 grid2(grid_x, split ? static_cast<unsigned>(a.split_k > 1 ? a.split_k : 1) : 1u);
     if (a.conv_mode != 0) {

@@ -71,15 +71,16 @@ struct Problem {
 static void launch_large(const GemmArgs& a, hipStream_t st, bool streaming = false) {
   using namespace dpa::kernels;
   static unsigned* counter = nullptr;
-  if (!counter) CK(hipMalloc(&counter, 16));
+  if (!counter) CK(hipMalloc(&counter, 32));  // one counter per XCD segment
   const bool split = a.split_k > 1 && a.workspace;
   const int tm = static_cast<int>((a.M + 255) / 256), tn = static_cast<int>((a.N + 255) / 256);
   const long long nk = a.K / 64;
   const int k_iters = split ? static_cast<int>((nk + a.split_k - 1) / a.split_k) : static_cast<int>(nk);
-  streaming = streaming && !split && nk >= 3;
-  if (streaming) CK(hipMemsetAsync(counter, 0, 16, st));
+  streaming = streaming && !split && nk >= 3 && tm * tn >= 64;
+  if (streaming) CK(hipMemsetAsync(counter, 0, 32, st));
   unsigned* ctr = streaming ? counter : nullptr;
-  const dim3 grid(streaming ? std::min(tm * tn, 256) : tm * tn, split ? a.split_k : 1);
+  // streaming: the same number W of workgroups on every XCD, and 2 W ids in each of the eight segments of the id list
+  const dim3 grid(streaming ? std::min(256, 4 * (tm * tn / 8)) & ~7 : tm * tn, split ? a.split_k : 1);
   const size_t lds = kLdsBytes2;
   auto go = [&](auto ak, auto bk) {
     constexpr bool AK = decltype(ak)::value, BKM = decltype(bk)::value;

@@ -502,9 +502,38 @@ def test_gemm_bf16_large_tile_kernel_exact_integers(a_k, b_k, M, N, K):
     assert torch.equal(out.double(), ref)
 
 
-def test_gemm_bf16_large_tile_fused_epilogue():
+@pytest.mark.parametrize("a_k,b_k", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("M,N,K,busy", [(16384, 3072, 192, False), (16500, 3080, 256, False), (24576, 2304, 192, True)])
+def test_gemm_bf16_streaming_walk_exact_integers(a_k, b_k, M, N, K, busy):
+    """>= 3 tiles per CU: one workgroup per CU walks the tiles, each XCD through its own segment of the id list
+    (845 tiles: segments of 106 and 105 ids, ragged last row / column of tiles).  `busy`: a second stream keeps
+    the chip occupied meanwhile, so workgroups of the product start late and segments are handed over."""
+    torch.manual_seed(M + N + K)
+    Af = torch.randint(-2, 3, (M, K), device=DEV).float()
+    Bf = torch.randint(-1, 2, (K, N), device=DEV).float()
+    Af[:, 0] = (torch.arange(M, device=DEV) % 5 - 2).float()
+    Bf[0, :] = (torch.arange(N, device=DEV) % 3 - 1).float()
+    Aop = (Af if a_k else Af.t().contiguous()).bfloat16()
+    Bop = (Bf.t().contiguous() if b_k else Bf.contiguous()).bfloat16()
+    ref = Af.double() @ Bf.double()
+    assert ref.abs().max() < 256
+    if busy:
+        side = torch.cuda.Stream()
+        filler = torch.randn(64 * 1024 * 1024, device=DEV)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                filler.mul_(1.0001)
+    outs = [C().gemm(Aop, Bop, a_k, b_k) for _ in range(3)]
+    torch.cuda.synchronize()
+    for out in outs:
+        assert torch.equal(out.double(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 256), (16384, 3072, 256)])
+def test_gemm_bf16_large_tile_fused_epilogue(M, N, K):
+    """One tile per workgroup (128 tiles) and the streaming walk (768 tiles: bias fetched a tile ahead)."""
     torch.manual_seed(4)
-    M, N, K = 4096, 2048, 256
     x = torch.randn(M, K, device=DEV).bfloat16()
     w = (torch.randn(N, K, device=DEV) / 16).bfloat16()
     b = torch.randn(N, device=DEV).bfloat16()

@@ -19,6 +19,7 @@
 //     2*((k&3) + 4*((k>>3)&1)) so that the eight 4-row blocks a 32-lane half touches fall
 //     on disjoint bank ranges;
 //   * XCD-aware workgroup remap as in the fp32 kernel.
+#include <atomic>
 #include <type_traits>
 
 #include "device_utils.h"
@@ -289,14 +290,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(GemmArgs p, int 
 #define DPA_STAMP_REAL(i)
 #endif
 // -DGEMM_TILE_TIMES (tools/kernel_harness/gemm_bench.hip): wave 0 records the 100 MHz clock at the start (slot 0) and
-// behind the last store (slot 1) of each of its first 128 tiles into p.colsum_partial.
+// behind the last store (slot 1) of each of its first 128 tiles into p.colsum_partial (eight slots per tile: 2 = k-steps
+// done, 3 .. 6 = stations of the activation-backward epilogue, 7 = kernel entry).
 #ifdef GEMM_TILE_TIMES
 #define DPA_TILE_TIME(slot)                                                                                          \
   do {                                                                                                               \
     unsigned long long t_;                                                                                           \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                 \
     if (threadIdx.x == 0 && tile_no < 128)                                                                           \
-      reinterpret_cast<unsigned long long*>(p.colsum_partial)[(blockIdx.x * 128 + tile_no) * 2 + (slot)] = t_;       \
+      reinterpret_cast<unsigned long long*>(p.colsum_partial)[(blockIdx.x * 128ll + tile_no) * 8 + (slot)] = t_;     \
   } while (0)
 #else
 #define DPA_TILE_TIME(slot)
@@ -499,6 +501,20 @@ using lds_u32_ptr = volatile __attribute__((address_space(3))) unsigned*;
 // the kernel it does not survive the tile loop's register pressure: it is spilled, and a reload from scratch memory
 // is an ordinary memory operation -- the compiler waits for it with vmcnt(0), which also waits for every LDS-DMA
 // request and output store in flight (found twice per tile, in the cursor move and in front of the bias request).
+// The two GELU tables (index 0: Phi(x) for the forward epilogue, 1: GELU'(x) for the backward one), filled once per
+// device by gelu_tables_init_kernel; a workgroup copies the one it needs into LDS by LDS-DMA.  (Computing the 3840
+// entries in every workgroup took 3.6 us -- a tenth of a tile's time in the one-tile-per-workgroup backward epilogue.)
+__device__ float g_gelu_tables[2][2 * kGeluEntries];
+__global__ void gelu_tables_init_kernel() {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * kGeluEntries) return;
+  const bool neg = e >= kGeluEntries;
+  const unsigned bits = static_cast<unsigned>(kGeluLo + (neg ? e - kGeluEntries : e)) | (neg ? 0x8000u : 0u);
+  const float x = __uint_as_float(bits << 16);
+  g_gelu_tables[0][e] = normal_cdf(x);
+  g_gelu_tables[1][e] = gelu_grad(x);
+}
+
 __device__ __forceinline__ int fresh_lane() {
   int l;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
@@ -519,26 +535,20 @@ constexpr int kStreamingMaxKSteps = 64;  // beyond K = 4096 a tile is long enoug
 // fixing them per workgroup keeps the kernel balanced when another stream (a collective) holds some CUs.
 // CONV: 0 = plain product; 1 = operand A is the implicit 3x3-convolution view of a haloed image (NT layout);
 // 2 = operand B is that view for the weight gradient (split-K TN layout).  See GemmArgs::conv_mode.
-template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT, int CONV = 0>
+// ACTBWD: the activation-backward epilogue (GemmArgs::aux); an instantiation of its own, so that the plain products do
+// not carry its code and registers (as a run-time branch it cost the NT forward kernel 8 spilled registers).
+template <bool A_KMAJOR, bool B_KMAJOR, bool SPLIT, int CONV = 0, bool ACTBWD = false>
 __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p, int tiles_m, int tiles_n, int k_iters, unsigned* tile_counter) {
   static_assert(CONV == 0 || (CONV == 1 && A_KMAJOR && B_KMAJOR && !SPLIT) || (CONV == 2 && !A_KMAJOR && !B_KMAJOR && SPLIT),
                 "convolution views exist for the NT forward product and the split-K TN weight gradient");
+  static_assert(!ACTBWD || (!SPLIT && CONV == 0), "the activation-backward epilogue belongs to the plain single-pass product");
   extern __shared__ __attribute__((aligned(16))) char smem2[];  // [2 k-steps][B0 | A0 | B1 | A1][GELU table][staging][control]
   DPA_STAMP(0);
   DPA_STAMP_REAL(4);
+  [[maybe_unused]] int tile_no = 0;
+  DPA_TILE_TIME(7);
 
   float* gelu_tab = reinterpret_cast<float*>(smem2 + kRingBytes);
-  if (!SPLIT && (p.aux_mode == kActGelu || p.act == kActGelu)) {
-    // backward epilogue: GELU'(x); forward epilogue: Phi(x), so that GELU(x) = x * table[x]
-    const bool derivative = p.aux_mode == kActGelu;
-    for (int e = threadIdx.x; e < 2 * kGeluEntries; e += kThreads2) {
-      const bool neg = e >= kGeluEntries;
-      const unsigned bits = static_cast<unsigned>(kGeluLo + (neg ? e - kGeluEntries : e)) | (neg ? 0x8000u : 0u);
-      const float x = __uint_as_float(bits << 16);
-      gelu_tab[e] = derivative ? gelu_grad(x) : normal_cdf(x);
-    }
-    __syncthreads();
-  }
 
   const bool dynamic = !SPLIT && tile_counter != nullptr;
   const int ntiles = tiles_m * tiles_n;
@@ -577,6 +587,17 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   const int wr = wid >> 2, wc = wid & 3;
   const int wm = wr * 128, wn = wc * 64;
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)smem2));
+  if (!SPLIT && (ACTBWD ? p.aux_mode == kActGelu : p.act == kActGelu)) {
+    // backward epilogue: GELU'(x); forward epilogue: Phi(x), so that GELU(x) = x * table[x].  15 pieces of 1 KiB, two
+    // per wave: older than every operand request, so the prologue's counted wait and barrier publish them as well.
+    const char* src = reinterpret_cast<const char*>(g_gelu_tables[ACTBWD ? 1 : 0]);
+    const unsigned voff = static_cast<unsigned>(lane * 16);
+    for (int piece = wid; piece < kGeluTableBytes / 1024; piece += 8) {
+      const char* base = uniform_ptr(src + piece * 1024);
+      const unsigned dst = lds_base + kRingBytes + piece * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory");
+    }
+  }
 
   const long long nk_all = p.K / BK2;
   const long long kt0 = SPLIT ? static_cast<long long>(split_idx) * k_iters : 0;
@@ -609,7 +630,8 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     first_id = seg_start + static_cast<int>(blockIdx.x >> 3);  // the launcher keeps 2 W <= seg_len
   }
   int cur = first_id;                                                                              // tile being multiplied
-  int nxt = dynamic ? seg_start + seg_w + static_cast<int>(blockIdx.x >> 3) : kNoTile;             // tile after it
+  const int seg_static = 2 * seg_w;  // local indices handed out without a draw, per segment
+  int nxt = dynamic ? seg_start + seg_w + static_cast<int>(blockIdx.x >> 3) : kNoTile;  // tile after it
   // per-lane source offsets of the cursor's tile (recomputed after every epilogue rather than kept across it)
   auto set_offsets = [&](int id) __attribute__((always_inline)) {
     long long rm0, rn0;
@@ -716,7 +738,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   // so its latency hides behind that step's MFMAs; the second half follows once the operand buffers are
   // dead.  LDS position (lane & 7) of row (lane >> 3) receives chunk (lane & 7) ^ (lane >> 3) of the row
   // (XOR on the source address), which spreads the accumulator-layout reads of the epilogue over the banks.
-  const bool act_bwd = !SPLIT && p.aux_mode != kActNone;
+  constexpr bool act_bwd = ACTBWD;
   long long m0, n0;  // origin of the tile being multiplied
   auto aux_request = [&](int half, int buf) __attribute__((always_inline)) {
     const int al = fresh_lane();
@@ -850,7 +872,29 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
   phase_barrier();
   DPA_STAMP(1);
 
-  [[maybe_unused]] int tile_no = 0;
+  // The id behind the drawn value in the control word; when this segment is used up (a handful of times per workgroup,
+  // at the end of the kernel) the next segments' counters are drawn from, waiting for each answer -- every wave takes
+  // that path together, the value it branches on being the workgroup's.
+  auto next_from_segments = [&]() __attribute__((always_inline)) -> int {
+    unsigned local = static_cast<unsigned>(seg_static) + __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
+    while (local >= static_cast<unsigned>(seg_len) && seg_hops < 7) {
+      ++seg_hops;
+      seg = (seg + 1) & 7;
+      seg_range(seg);
+      phase_barrier();  // every wave has read the control word
+      if (threadIdx.x == 0) {
+        const unsigned one = 1u, zero = 0u;
+        unsigned got;
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(zero), "v"(one), "s"(tile_counter + seg) : "memory");
+        *(lds_u32_ptr)(smem2 + kCtrlOff) = got;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      phase_barrier();
+      local = static_cast<unsigned>(seg_static) + __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
+    }
+    return local < static_cast<unsigned>(seg_len) ? seg_start + static_cast<int>(local) : kNoTile;
+  };
+
   while (true) {
     DPA_STAMP(6);
     DPA_TILE_TIME(0);
@@ -898,6 +942,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     }
     if (wr == 0) phase_barrier();
     DPA_STAMP(2);
+    DPA_TILE_TIME(2);
     // Every wave is done with the last k-step's buffer: its A1 slot can take the next tile's second k-step
     // now, ahead of this tile's output stores in the memory queue.
     a1_ahead = dynamic && r_valid;
@@ -927,7 +972,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       // cells, and the rows then leave as 8 rows x 128 contiguous bytes per store instruction -- so
       // neither direction touches global memory with the accumulator layout's 32-byte row pieces.
       phase_barrier();                     // every wave has finished reading the operand buffers
-      const int last = (n - 1) & 1;        // buffer of the last k-step; half 0 sits in the other one
+      const int last = c_buf ^ 1;          // buffer of the last k-step (c_buf points past it); half 0 sits in the other one
       aux_request(1, last);
       u16* Cout = static_cast<u16*>(p.C);
       float csum = 0.f;  // lane c: column n0 + wn + c of this wave's 128 rows
@@ -978,12 +1023,19 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       char* img1 = smem2 + last * 2 * kTileBytes2 + wid * 8192;
       // a wave only ever touches its own two images, and the DMA counts as complete once its data is in LDS
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      DPA_TILE_TIME(3);
       process(0, img0);
+      DPA_TILE_TIME(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // before any store is in flight: the second half has landed
+      DPA_TILE_TIME(5);
       store_rows(0, img0);
       process(1, img1);
+      DPA_TILE_TIME(6);
       store_rows(1, img1);
+#ifndef GEMM_TILE_TIMES
       if (p.colsum_partial) p.colsum_partial[(2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + el] = csum;
+#endif
+      DPA_TILE_TIME(1);
       return;
     }
     if (staged) {
@@ -1104,25 +1156,7 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
     // next tile: the id drawn while this one was multiplied becomes the one after it
     cur = nxt;
     if (cur >= ntiles) return;
-    unsigned local = 2u * seg_w + __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
-    // Segment used up (a handful of times per workgroup, at the end of the kernel): draw from the next ones, waiting
-    // for each answer -- every wave takes this path together, the value it branches on being the workgroup's.
-    while (local >= static_cast<unsigned>(seg_len) && seg_hops < 7) {
-      ++seg_hops;
-      seg = (seg + 1) & 7;
-      seg_range(seg);
-      phase_barrier();  // every wave has read the control word
-      if (threadIdx.x == 0) {
-        const unsigned one = 1u, zero = 0u;
-        unsigned got;
-        asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(zero), "v"(one), "s"(tile_counter + seg) : "memory");
-        *(lds_u32_ptr)(smem2 + kCtrlOff) = got;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      phase_barrier();
-      local = 2u * seg_w + __builtin_amdgcn_readfirstlane(*(lds_u32_ptr)(smem2 + kCtrlOff));
-    }
-    nxt = local < static_cast<unsigned>(seg_len) ? seg_start + static_cast<int>(local) : kNoTile;
+    nxt = next_from_segments();
     set_offsets(cur);  // the cursor is inside this tile
   }
 }
@@ -1237,6 +1271,13 @@ StreamingSetup& streaming_setup() {
 // Several tiles per workgroup pay off when a tile is short (few k-steps): the cold start and the
 // drain of a workgroup are then a visible share of its time.
 bool use_streaming(const GemmArgs& a, long long tiles, bool split) {
+#ifdef GEMM_NO_STREAMING  // experiment (tools/kernel_harness): one tile per workgroup whatever the shape
+  return false;
+#endif
+  // The activation-backward epilogue needs both LDS buffers: one tile per workgroup.  (Walking the tiles with it as
+  // well -- next tile's id drawn during the k-steps, its first two k-steps requested from inside the epilogue as the
+  // buffers fall free -- was built and measured: 2152 -> 2120 us standalone on 393216 x 3072 x 768, nothing in the
+  // training step; the workgroups then wait for their aux tiles and stores together instead of being relaunched.)
   if (split || a.aux_mode != kActNone) return false;
   const long long nk = a.K / BK2;
   const StreamingSetup& s = streaming_setup();
@@ -1259,7 +1300,25 @@ bool gemm_bf16_conv_supported(const GemmArgs& a) {
          a.M % 8 == 0 && a.M >= 8 && a.lda % 8 == 0 && a.workspace != nullptr && a.split_k >= 1;
 }
 
+// Fills g_gelu_tables on the current device the first time a launch needs them (on that launch's stream).
+void ensure_gelu_tables(hipStream_t stream) {
+  static std::atomic<unsigned> done{0};  // bit d: device d is initialised
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned bit = 1u << (dev & 31);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  hipLaunchKernelGGL(gelu_tables_init_kernel, dim3((2 * kGeluEntries + 255) / 256), dim3(256), 0, stream);
+  // Later launches on OTHER streams must see the tables too: wait once.  Inside a stream capture no wait is
+  // possible -- the fill then becomes part of the graph (in front of the product that needs it) and the device
+  // stays unmarked, so the next launch outside a capture fills and waits.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+  (void)hipStreamSynchronize(stream);
+  done.fetch_or(bit, std::memory_order_release);
+}
+
 void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
+  if (a.act == kActGelu || a.aux_mode == kActGelu) ensure_gelu_tables(stream);
   const bool split = (a.split_k > 1 || a.conv_mode == 2) && a.workspace != nullptr;
   // the activation-backward epilogue exists in the large-tile kernel only (callers check
   // gemm_bf16_act_backward_supported first)
@@ -1310,12 +1369,16 @@ void launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<AK, BKM, false, 0, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes2);
         configured = true;
       }
       if (split) {
         hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, true>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters, counter);
         const long long quads = a.M * (a.N >> 2);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, stream, a);
+      } else if (a.aux_mode != kActNone) {
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, false, 0, true>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters, counter);
       } else {
         hipLaunchKernelGGL((gemm_bf16_8ph_kernel<AK, BKM, false>), grid2, dim3(kThreads2), lds2, stream, a, tm2, tn2, k_iters, counter);
       }

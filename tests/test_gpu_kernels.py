@@ -939,6 +939,34 @@ def test_dgrad_act_backward_gelu_table_over_all_magnitudes():
     torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-2, atol=0.15)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(16384, 3072, 192, "gelu"), (20480, 2560, 256, "relu"), (16384, 3072, 768, "gelu")])
+def test_dgrad_act_backward_many_tiles(M, N, K, act):
+    """Several waves of workgroups (>= 3 tiles per CU, the benchmark's regime): input gradient and its column sums
+    against fp64 on random pre-activations (every table entry in use), three runs bit-equal."""
+    from distributed_pytorch_amd.ops.linear import ACT_GELU, ACT_RELU
+
+    torch.manual_seed(M + N + K)
+    dy = torch.randn(M, K, device=DEV).bfloat16()
+    w = (torch.randn(K, N, device=DEV) / 8).bfloat16()
+    aux = (torch.randn(M, N, device=DEV) * 1.5).bfloat16()
+    assert C().dgrad_act_backward_supported(M, N, K)
+    code = ACT_GELU if act == "gelu" else ACT_RELU
+    runs = [C().dgrad_act_backward(dy, w, aux, code, True) for _ in range(3)]
+    torch.cuda.synchronize()
+    g, db = runs[0]
+    for g2, db2 in runs[1:]:
+        assert torch.equal(g, g2) and torch.equal(db, db2)
+    x = aux.double()
+    if act == "gelu":
+        d = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    else:
+        d = (x > 0).double()
+    ref = (dy.double() @ w.double()) * d
+    err = (g.double() - ref).abs()
+    assert (err <= 8e-3 * ref.abs() + 4e-3).all(), err.max().item()
+    torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-2, atol=0.02 * math.sqrt(M))
+
+
 # ----------------------------------------------------------------------------- batch normalisation (channels last)
 @pytest.mark.parametrize("shape", [(8, 64, 28, 28), (3, 64, 7, 5), (4, 256, 14, 14), (2, 2048, 7, 7), (5, 512, 3, 3), (16, 128, 1, 1)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -1,11 +1,11 @@
 """Lists, per basic block of one gemm_bf16_8ph_kernel instantiation, the full memory drains (s_waitcnt vmcnt(0)) and
 scratch accesses -- a spilled value reloaded inside the tile loop costs such a drain.
-usage: python tools/gemm_asm_drains.py file.s [template-args, default 'ILb1ELb1ELb0ELi0E']"""
+usage: python tools/gemm_asm_drains.py file.s [template-args, default 'ILb1ELb1ELb0ELi0ELb0E']"""
 import re
 import sys
 
 path = sys.argv[1]
-inst = sys.argv[2] if len(sys.argv) > 2 else "ILb1ELb1ELb0ELi0E"
+inst = sys.argv[2] if len(sys.argv) > 2 else "ILb1ELb1ELb0ELi0ELb0E"
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if "gemm_bf16_8ph_kernel" + inst in l and l.startswith("_ZN"))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))

@@ -4,7 +4,7 @@
 #include <cstring>
 #include <vector>
 #include GEMM_SRC
-// args: M N K [epilogue: 0 plain, 1 bias, 2 bias + GELU, 3 bias + GELU + pre-activation output]
+// args: M N K [epilogue: 0 plain, 1 bias, 2 bias + GELU, 3 bias + GELU + pre-activation output, 4 activation backward]
 // With -DDPA_GEMM_STAMPS: cycles of the last tile's k-loop and epilogue, averaged over the workgroups.
 int main(int argc, char** argv) {
   const long long M = argc > 1 ? atoll(argv[1]) : 8192, N = argc > 2 ? atoll(argv[2]) : 8192, K = argc > 3 ? atoll(argv[3]) : 8192;
@@ -18,9 +18,14 @@ int main(int argc, char** argv) {
   hipMemcpy(B, h.data(), N * K * 2, hipMemcpyHostToDevice);
   dpa::kernels::GemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N; a.a_kmajor = 1; a.b_kmajor = 1; a.alpha = 1.f;
-  if (epi >= 1) { hipMalloc(&bias, N * 2); hipMemset(bias, 0, N * 2); a.bias = bias; }
-  if (epi >= 2) a.act = dpa::kernels::kActGelu;
-  if (epi >= 3) { hipMalloc(&P, M * N * 2); a.pre_act = P; }
+  if (epi >= 1 && epi <= 3) { hipMalloc(&bias, N * 2); hipMemset(bias, 0, N * 2); a.bias = bias; }
+  if (epi == 2 || epi == 3) a.act = dpa::kernels::kActGelu;
+  if (epi == 3) { hipMalloc(&P, M * N * 2); a.pre_act = P; }
+  if (epi == 4) {  // activation-backward epilogue: C = acc * GELU'(aux), one tile per workgroup
+    hipMalloc(&P, M * N * 2); hipMemset(P, 0, M * N * 2);
+    a.aux = P; a.aux_mode = dpa::kernels::kActGelu;
+    if (!dpa::kernels::gemm_bf16_act_backward_supported(a)) { printf("activation-backward epilogue: shape not supported\n"); return 1; }
+  }
 #ifdef DPA_GEMM_STAMPS
   unsigned long long* stamps;
   hipMalloc(&stamps, 4096 * 8 * 8); hipMemset(stamps, 0, 4096 * 8 * 8);
@@ -28,7 +33,9 @@ int main(int argc, char** argv) {
 #endif
 #ifdef GEMM_TILE_TIMES
   unsigned long long* times;
-  hipMalloc(&times, 256 * 128 * 2 * 8); hipMemset(times, 0, 256 * 128 * 2 * 8);
+  const long long kTimeWgs = epi == 4 ? (M / 256) * (N / 256) : 256;         // workgroups that record
+  const size_t kTimeBytes = static_cast<size_t>(kTimeWgs) * 128 * 8 * 8;   // [workgroup][tile < 128][slot < 8]
+  hipMalloc(&times, kTimeBytes); hipMemset(times, 0, kTimeBytes);
   a.colsum_partial = reinterpret_cast<float*>(times);
 #endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -49,31 +56,43 @@ int main(int argc, char** argv) {
                 n, loop / n, ep / n, life / n / 100.0);
 #endif
 #ifdef GEMM_TILE_TIMES
-  {  // where in its tile period is every workgroup when workgroup 0 starts tile k?  (spread = phases differ; one pile = in step)
-    hipMemset(times, 0, 256 * 128 * 2 * 8);
+  {
+    hipMemset(times, 0, kTimeBytes);
     dpa::kernels::launch_gemm_bf16(a, 0);
     hipDeviceSynchronize();
-    std::vector<unsigned long long> t(256 * 128 * 2);
-    hipMemcpy(t.data(), times, t.size() * 8, hipMemcpyDeviceToHost);
-    auto T = [&](int wg, int tile, int slot) { return t[(wg * 128 + tile) * 2 + slot]; };
+    std::vector<unsigned long long> t(kTimeBytes / 8);
+    hipMemcpy(t.data(), times, kTimeBytes, hipMemcpyDeviceToHost);
+    auto T = [&](long long wg, int tile, int slot) { return t[(wg * 128 + tile) * 8 + slot]; };
+    if (epi == 4) {  // one tile per workgroup: stations of the activation-backward epilogue, mean over the workgroups
+      const char* names[7] = {"entry -> tile start (table, offsets)", "tile start -> k-steps done", "k-steps done -> first aux half landed", "first half processed",
+                              "second aux half landed", "first half stored + second processed", "second half stored"};
+      const int order[8] = {7, 0, 2, 3, 4, 5, 6, 1};
+      double sum[7] = {0}; long long n = 0;
+      for (long long w = 0; w < kTimeWgs; ++w) {
+        if (!T(w, 0, 1)) continue;
+        for (int i = 0; i < 7; ++i) sum[i] += double(T(w, 0, order[i + 1]) - T(w, 0, order[i]));
+        ++n;
+      }
+      for (int i = 0; i < 7; ++i) printf("  %-40s %6.2f us\n", names[i], sum[i] / n / 100.0);
+      return 0;
+    }
+    // where in its tile period is every workgroup when workgroup 0 ends tile k?  (spread = phases differ; one pile = in step)
     int ntile = 0; while (ntile < 128 && T(0, ntile, 1)) ++ntile;
     const double period = double(T(0, ntile - 1, 1) - T(0, 0, 0)) / ntile;
-    printf("  workgroup 0: %d tiles, %.2f us per tile; epilogue (first convert -> last store issued) mean %.2f us\n", ntile, period / 100.0,
-           [&] { double s = 0; int n = 0; for (int w = 0; w < 256; ++w) for (int k = 0; k < 128 && T(w, k, 1); ++k) { s += double(T(w, k, 1) - T(w, k, 0)); ++n; } return n ? s / n / 100.0 : 0.0; }());
-    printf("  (slot 0 is the tile start, slot 1 the end of its epilogue: the difference above is the whole tile)\n");
+    printf("  workgroup 0: %d tiles, %.2f us per tile, of which k-steps %.2f us\n", ntile, period / 100.0,
+           [&] { double s = 0; int n = 0; for (int w = 0; w < 256; ++w) for (int k = 0; k < 128 && T(w, k, 1); ++k) { s += double(T(w, k, 2) - T(w, k, 0)); ++n; } return n ? s / n / 100.0 : 0.0; }());
     for (int k : {1, 5, 10, 20, 40, 60}) {
       if (k >= ntile) break;
       const unsigned long long ref = T(0, k, 1);
       int hist[8] = {0};
       for (int w = 0; w < 256; ++w) {
-        // the end of the epilogue of workgroup w nearest to ref
-        long long best = 1ll << 60;
+        long long best = 1ll << 60;  // the end of a tile of workgroup w nearest to ref
         for (int j = 0; j < 128 && T(w, j, 1); ++j) { const long long d = (long long)(T(w, j, 1) - ref); if (llabs(d) < llabs(best)) best = d; }
         double ph = best / period + 0.5;  // 0 .. 1 around the reference
         if (ph < 0) ph = 0; if (ph > 0.999) ph = 0.999;
         ++hist[int(ph * 8)];
       }
-      printf("  around tile %2d of workgroup 0, epilogue ends by eighth of a period (4 = together with it):", k);
+      printf("  around tile %2d of workgroup 0, tile ends by eighth of a period (4 = together with it):", k);
       for (int h = 0; h < 8; ++h) printf(" %3d", hist[h]);
       printf("\n");
     }

@@ -975,7 +975,11 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       const int last = c_buf ^ 1;          // buffer of the last k-step (c_buf points past it); half 0 sits in the other one
       aux_request(1, last);
       u16* Cout = static_cast<u16*>(p.C);
-      float csum = 0.f;  // lane c: column n0 + wn + c of this wave's 128 rows
+      // Column sums of the bf16-rounded results: each lane adds up its own rows of its 16 columns (16 j + 4 g + e) as it
+      // produces them, and the 16 lanes of a row group are summed by rotations at the end -- no LDS traffic (read back
+      // from the images the sums were 64 of the 160 LDS instructions per lane and half of the epilogue).
+      float cs[4][4] = {};
+      const bool want_colsum = p.colsum_partial != nullptr;
       const int el = fresh_lane();
       const int r = el & 15, g = el >> 4;
       const bool gelu = p.aux_mode == kActGelu;
@@ -1004,12 +1008,11 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = BF16::from_f32(a[e] * d[e]);
             *reinterpret_cast<u16x4*>(cell) = o;  // same lane, same cell: read before write by program order
+            if (want_colsum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) cs[j][e] += BF16::to_f32(o[e]);
+            }
           }
-        if (p.colsum_partial) {
-#pragma unroll 8
-          for (int rr = 0; rr < 64; ++rr)
-            csum += BF16::to_f32(*reinterpret_cast<const u16*>(img + rr * 128 + (((el >> 3) ^ (rr & 7)) << 4) + (el & 7) * 2));
-        }
       };
       auto store_rows = [&](int half, const char* img) __attribute__((always_inline)) {
 #pragma unroll
@@ -1033,7 +1036,26 @@ __global__ __launch_bounds__(kThreads2, 2) void gemm_bf16_8ph_kernel(GemmArgs p,
       DPA_TILE_TIME(6);
       store_rows(1, img1);
 #ifndef GEMM_TILE_TIMES
-      if (p.colsum_partial) p.colsum_partial[(2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + el] = csum;
+      if (want_colsum) {
+        auto rot = [](float v, auto n_c) __attribute__((always_inline)) {  // v of the lane n places on in its group of 16
+          constexpr int ctrl = 0x120 + decltype(n_c)::value;                 // row_ror:n
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = cs[j][e];
+            v += rot(v, std::integral_constant<int, 8>{});
+            v += rot(v, std::integral_constant<int, 4>{});
+            v += rot(v, std::integral_constant<int, 2>{});
+            v += rot(v, std::integral_constant<int, 1>{});
+            out[e] = v;
+          }
+          if (r == 0) *reinterpret_cast<f32x4*>(p.colsum_partial + (2 * (m0 / BM2) + (wid >> 2)) * p.N + n0 + wn + 16 * j + 4 * g) = out;
+        }
+      }
 #endif
       DPA_TILE_TIME(1);
       return;

@@ -1,4 +1,5 @@
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,7 +23,13 @@ int main(int argc, char** argv) {
   if (epi == 2 || epi == 3) a.act = dpa::kernels::kActGelu;
   if (epi == 3) { hipMalloc(&P, M * N * 2); a.pre_act = P; }
   if (epi == 4) {  // activation-backward epilogue: C = acc * GELU'(aux), one tile per workgroup
-    hipMalloc(&P, M * N * 2); hipMemset(P, 0, M * N * 2);
+    hipMalloc(&P, M * N * 2);
+    {  // pre-activations spread over +-4, so that the table look-ups of a wave go to different entries
+      std::vector<unsigned short> hx(1 << 20);
+      for (auto& x : hx) { float f = (rand() / (float)RAND_MAX - 0.5f) * 8.f; unsigned u; memcpy(&u, &f, 4); x = u >> 16; }
+      for (long long off = 0; off < M * N; off += (1 << 20))
+        hipMemcpy(P + off, hx.data(), std::min<long long>(1 << 20, M * N - off) * 2, hipMemcpyHostToDevice);
+    }
     a.aux = P; a.aux_mode = dpa::kernels::kActGelu;
     if (!dpa::kernels::gemm_bf16_act_backward_supported(a)) { printf("activation-backward epilogue: shape not supported\n"); return 1; }
   }

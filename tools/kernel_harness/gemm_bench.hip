@@ -75,12 +75,19 @@ int main(int argc, char** argv) {
                               "second aux half landed", "first half stored + second processed", "second half stored"};
       const int order[8] = {7, 0, 2, 3, 4, 5, 6, 1};
       double sum[7] = {0}; long long n = 0;
+      double whole = 0; long long nw = 0;  // later tiles of a workgroup that walks: start of one tile to start of the next
       for (long long w = 0; w < kTimeWgs; ++w) {
         if (!T(w, 0, 1)) continue;
         for (int i = 0; i < 7; ++i) sum[i] += double(T(w, 0, order[i + 1]) - T(w, 0, order[i]));
         ++n;
+        for (int k = 1; k < 127 && T(w, k + 1, 0); ++k) {
+          for (int i = 1; i < 7; ++i) sum[i] += double(T(w, k, order[i + 1]) - T(w, k, order[i]));
+          whole += double(T(w, k + 1, 0) - T(w, k, 0));
+          ++nw;
+        }
       }
-      for (int i = 0; i < 7; ++i) printf("  %-40s %6.2f us\n", names[i], sum[i] / n / 100.0);
+      printf("  first tiles %lld, later tiles %lld (%.2f us from tile start to tile start)\n", n, nw, nw ? whole / nw / 100.0 : 0.0);
+      for (int i = 0; i < 7; ++i) printf("  %-40s %6.2f us\n", names[i], sum[i] / (i ? n + nw : n) / 100.0);
       return 0;
     }
     // where in its tile period is every workgroup when workgroup 0 ends tile k?  (spread = phases differ; one pile = in step)
